@@ -1,0 +1,328 @@
+"""Host driver of the VB-NMF path: a Python mirror of the reference's R driver functions,
+with the native step running on the MI355X engine instead of ``.Call(_ccfindR_vbnmf_update)``.
+
+Mirrors (same names, argument meaning and error behaviour as the reference; R's dots in
+argument names become underscores):
+
+* ``vbnmf_update(X, wh, hyper, fudge)``   reference R/RcppExports.R:4-6 -> src/vbnmf_update.cpp:16-101
+* ``hyper_update(...)``                    reference R/bayesian.R:2-53
+* ``vb_init(...)``                         reference R/bayesian.R:109-171 (``random``, ``svd2``)
+* ``vb_iterate(irun, bundle)``             reference R/bayesian.R:303-390
+* ``vb_factorize(...)``                    reference R/bayesian.R:229-301
+
+What is deliberately NOT here: the scNMFSet S4 container, connectivity/dispersion
+(reference R/factorize.R:51-78, O(m^2) post-processing) and Rmpi.  ``vb_factorize`` takes the
+count matrix itself and returns a plain result object holding the slots the reference fills.
+"""
+from __future__ import annotations
+
+import math
+import warnings
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _native as N
+from .engine import EPS, CountMatrix, VBEngine
+
+import ctypes
+
+
+# ---------------------------------------------------------------------------------------
+# scalar digamma / trigamma for the hyper-parameter Newton step (host side, a few calls
+# per iteration): R's digamma() and psigamma(x, 1) at reference R/bayesian.R:19-24.
+# ---------------------------------------------------------------------------------------
+def _digamma(x: float) -> float:
+    if not x > 0.0:
+        return float("nan")
+    s = 0.0
+    while x < 10.0:
+        s -= 1.0 / x
+        x += 1.0
+    xi = 1.0 / x
+    y = xi * xi
+    ser = y * (1 / 12 - y * (1 / 120 - y * (1 / 252 - y * (1 / 240 - y * (1 / 132 - y * (691 / 32760 - y / 12))))))
+    return s + math.log(x) - 0.5 * xi - ser
+
+
+def _trigamma(x: float) -> float:
+    if not x > 0.0:
+        return float("nan")
+    s = 0.0
+    while x < 10.0:
+        s += 1.0 / (x * x)
+        x += 1.0
+    xi = 1.0 / x
+    y = xi * xi
+    ser = xi * y * (1 / 6 - y * (1 / 30 - y * (1 / 42 - y * (1 / 30 - y * (5 / 66 - y * (691 / 2730 - y * (7 / 6)))))))
+    return s + xi + 0.5 * y + ser
+
+
+# ---------------------------------------------------------------------------------------
+def vbnmf_update(X, wh, hyper, fudge=EPS):
+    """One update step, stateless: the reference's ``vbnmf_update(X, wh, hyper, fudge)``.
+
+    ``X``: dense array (what ``as.matrix`` hands the reference) or scipy sparse matrix.
+    ``wh``: mapping with ``lw`` (n x r), ``lh`` (r x m), ``eh`` (r x m) (``ew`` is accepted and
+    ignored, as the reference overwrites it before use, src/vbnmf_update.cpp:24,44).
+    ``hyper``: mapping with ``aw, bw, ah, bh``.  Returns the reference's list
+    ``w, h, lw, lh, ew, eh, lkh, dw, dh`` (src/vbnmf_update.cpp:92-100) as a dict.
+    """
+    L = N.load()
+    for key in ("lw", "lh", "eh"):
+        if key not in wh:
+            raise KeyError(f"wh has no member '{key}'")          # Rcpp: index out of bounds
+    for key in ("aw", "bw", "ah", "bh"):
+        if key not in hyper:
+            raise KeyError(f"hyper has no member '{key}'")
+    fud = float(np.asarray(fudge, dtype=np.float64).ravel()[0])  # fudge[0], src/vbnmf_update.cpp:19
+    lw0, lh0, eh0 = N.fcol(wh["lw"]), N.fcol(wh["lh"]), N.fcol(wh["eh"])
+    n, r = lw0.shape
+    m = lh0.shape[1]
+    if lh0.shape != (r, m) or eh0.shape != (r, m):
+        raise ValueError("wh members have inconsistent shapes")
+    lw = np.empty((n, r), order="F"); ew = np.empty((n, r), order="F"); dw = np.empty((n, r), order="F")
+    lh = np.empty((r, m), order="F"); eh = np.empty((r, m), order="F"); dh = np.empty((r, m), order="F")
+    lkh = ctypes.c_double()
+    hy = [float(hyper[k]) for k in ("aw", "bw", "ah", "bh")]
+    if hasattr(X, "tocsc"):
+        S = X.tocsc()
+        if S.shape != (n, m):
+            raise ValueError("X and wh have inconsistent shapes")
+        p = np.ascontiguousarray(S.indptr, dtype=np.int32)
+        i = np.ascontiguousarray(S.indices, dtype=np.int32)
+        x = np.ascontiguousarray(S.data, dtype=np.float64)
+        N.check(L.vbnmf_update_csc(n, m, r, p.ctypes.data_as(N.c_int32_p), i.ctypes.data_as(N.c_int32_p), N.dptr(x),
+                                   N.dptr(lw0), N.dptr(lh0), N.dptr(eh0), *hy, fud,
+                                   N.dptr(lw), N.dptr(lh), N.dptr(ew), N.dptr(eh), N.dptr(dw), N.dptr(dh),
+                                   ctypes.byref(lkh)))
+    else:
+        A = N.fcol(X)
+        if A.shape != (n, m):
+            raise ValueError("X and wh have inconsistent shapes")
+        N.check(L.vbnmf_update_dense(n, m, r, N.dptr(A), N.dptr(lw0), N.dptr(lh0), N.dptr(eh0), *hy, fud,
+                                     N.dptr(lw), N.dptr(lh), N.dptr(ew), N.dptr(eh), N.dptr(dw), N.dptr(dh),
+                                     ctypes.byref(lkh)))
+    return {"w": ew, "h": eh, "lw": lw, "lh": lh, "ew": ew, "eh": eh, "lkh": lkh.value, "dw": dw, "dh": dh}
+
+
+def hyper_update(hyper_update, wh, hyper, Niter=100, Tol=1e-4):
+    """Newton update of the Gamma shapes and the means; reference R/bayesian.R:2-53.
+
+    ``wh`` is either the reference's list (``lw, lh, ew, eh`` matrices) or the 4-tuple of
+    their reductions ``(mean log lw, mean log lh, mean ew, mean eh)`` the engine returns.
+    """
+    flags = [bool(f) for f in hyper_update]
+    if sum(flags) == 0:                                          # :4
+        return dict(hyper)
+    aw0, ah0 = float(hyper["aw"]), float(hyper["ah"])
+    if isinstance(wh, dict):
+        lwm = float(np.mean(np.log(wh["lw"]))); lhm = float(np.mean(np.log(wh["lh"])))   # :8-9
+        ewm = float(np.mean(wh["ew"])); ehm = float(np.mean(wh["eh"]))                   # :10-11
+    else:
+        lwm, lhm, ewm, ehm = (float(v) for v in wh)
+    bw0, bh0 = float(hyper["bw"]), float(hyper["bh"])
+    if flags[0] + flags[2] > 0:                                  # :15
+        i = 1
+        while i < Niter:                                         # :17
+            dw = ((math.log(aw0) - _digamma(aw0) - ewm / bw0 + 1 + lwm - math.log(bw0))
+                  / (1 / aw0 - _trigamma(aw0))) if flags[0] else 0.0
+            dh = ((math.log(ah0) - _digamma(ah0) - ehm / bh0 + 1 + lhm - math.log(bh0))
+                  / (1 / ah0 - _trigamma(ah0))) if flags[2] else 0.0
+            aw1, ah1 = aw0 - dw, ah0 - dh
+            while aw1 <= 0:                                      # :28-31
+                dw /= 2
+                aw1 = aw0 - dw
+            while ah1 <= 0:                                      # :32-35
+                dh /= 2
+                ah1 = ah0 - dh
+            df = (1 - aw1 / aw0) ** 2 + (1 - ah1 / ah0) ** 2     # :37
+            if df < Tol:
+                break
+            aw0, ah0 = aw1, ah1
+            i += 1
+        if i == Niter:                                           # :43
+            raise RuntimeError("Hyper-parameter update failed to converge")
+    else:
+        aw1, ah1 = aw0, ah0
+    bw1 = ewm if flags[1] else bw0                               # :48-49
+    bh1 = ehm                                                    # :50-51 (both branches assign ehm)
+    return {"aw": aw1, "bw": bw1, "ah": ah1, "bh": bh1}
+
+
+def vb_init(nrow, ncol, mat, rank, hyper, initializer, max=1.0, rng=None):
+    """Initial ``wh``; reference R/bayesian.R:109-171.  ``random`` draws from the Gamma priors
+    with a numpy Generator (R's RNG stream cannot be reproduced outside R); ``svd2`` takes
+    |U| and |D V^T| of a rank-``rank`` SVD rescaled so mean(h) = bh."""
+    if initializer == "random":
+        if rng is None:
+            rng = np.random.default_rng()
+        w = rng.gamma(shape=hyper["aw"], scale=hyper["bw"] / hyper["aw"], size=(nrow, rank))   # :112-113
+        h = rng.gamma(shape=hyper["ah"], scale=hyper["bh"] / hyper["ah"], size=(rank, ncol))   # :114-115
+    elif initializer == "svd2":
+        if min(nrow, ncol) / 2 <= rank or not hasattr(mat, "tocsc"):
+            A = mat.toarray() if hasattr(mat, "toarray") else np.asarray(mat, dtype=np.float64)
+            u, d, vt = np.linalg.svd(A, full_matrices=False)                                    # :152
+            u, d, vt = u[:, :rank], d[:rank], vt[:rank]
+        else:
+            from scipy.sparse.linalg import svds
+            u, d, vt = svds(mat.astype(np.float64), k=rank)                                     # :154 (irlba)
+            o = np.argsort(-d)
+            u, d, vt = u[:, o], d[o], vt[o]
+        w = np.abs(u)                                                                           # :155
+        h = np.abs(np.diag(d) @ vt)                                                             # :156
+        scale = hyper["bh"] / np.mean(h)                                                        # :157
+        h = h * scale
+        w = w / scale
+    elif initializer == "svd":
+        raise NotImplementedError("initializer 'svd' (reference R/bayesian.R:116-149) is not built; use 'svd2' or 'random'")
+    else:
+        raise ValueError("Unknown initializer")                                                 # :160
+    dw = np.zeros((nrow, rank)); dh = np.zeros((rank, ncol))
+    return {"w": w, "h": h, "lw": w.copy(), "lh": h.copy(), "ew": w.copy(), "eh": h.copy(), "dw": dw, "dh": dh}
+
+
+@dataclass
+class VBResult:
+    """The slots vb_factorize fills in the reference's scNMFSet (reference R/bayesian.R:293-299)."""
+    ranks: list = field(default_factory=list)
+    basis: list = field(default_factory=list)      # E[W], n x r per rank
+    dbasis: list = field(default_factory=list)     # sd[W]
+    coeff: list = field(default_factory=list)      # E[H], r x m per rank
+    dcoeff: list = field(default_factory=list)     # sd[H]
+    measure: dict = field(default_factory=dict)    # columns rank, lml, aw, bw, ah, bh, nunif
+    nsteps: list = field(default_factory=list)     # iterations used by the selected run (not in the reference)
+
+
+def _bundle_rng(bundle, irun):
+    seed = bundle.get("seed")
+    return np.random.default_rng(None if seed is None else [int(seed), int(irun)])
+
+
+def vb_iterate(irun, bundle):
+    """One run over all ranks; reference R/bayesian.R:303-390 with the engine as the update."""
+    X = bundle["mat"]
+    nrow, ncol = X.shape
+    ranks = list(bundle["ranks"])
+    nrank = len(ranks)
+    rdat = [-math.inf] * nrank
+    wdat, hdat, dwdat, dhdat, hyperp, nsteps = {}, {}, {}, {}, {}, {}
+    nunif = [0] * nrank
+    verbose = bundle["verbose"]
+    if verbose >= 2 and bundle["nrun"] > 1:
+        print(f"Run {irun}")
+    ga, gb = np.atleast_1d(bundle["gamma_a"]), np.atleast_1d(bundle["gamma_b"])
+    rng = _bundle_rng(bundle, irun)
+    for irank in range(nrank):
+        rank = int(ranks[irank])
+        if rank > min(nrow, ncol):
+            raise ValueError("Rank exceeded min(nrow,ncol)")                     # :319-320
+        hyper = {"aw": float(ga[0]), "ah": float(ga[-1]), "bw": float(gb[0]), "bh": float(gb[-1])}   # :321-326
+        wh0 = vb_init(nrow, ncol, bundle.get("raw"), rank, hyper=hyper, initializer=bundle["initializer"], rng=rng)
+        eng = VBEngine(X, rank, device=bundle.get("device", 0))
+        try:
+            eng.set_state(wh0["lw"], wh0["lh"], wh0["eh"])
+            lk0 = 0.0
+            it = 0
+            for it in range(1, bundle["Itmax"] + 1):                             # :337
+                lkh, stats = eng.step(hyper, bundle["fudge"])                    # :339
+                if it > bundle["hyper_update_n0"] and it % bundle["hyper_update_dn"] == 0:   # :342
+                    hyper = hyper_update(bundle["hyper_update"], stats, hyper, Niter=100, Tol=1e-3)
+                if math.isnan(lkh):                                              # :345
+                    break
+                if it > 1 and it > bundle["hyper_update_n0"]:                    # :346-347
+                    if lkh >= lk0 and abs(1 - lkh / lk0) < bundle["Tol"]:
+                        break
+                lk0 = lkh                                                        # :348
+                if verbose >= 3:
+                    print(f"{it}, log(evidence) = {lk0}, aw = {hyper['aw']}, bw = {hyper['bw']}, "
+                          f"ah = {hyper['ah']}, bh = {hyper['bh']}")
+            wh = eng.get_state(("ew", "eh", "dw", "dh"))
+        finally:
+            eng.close()
+        if verbose >= 2:
+            print(f"Rank = {rank}: Nsteps ={it}, log(evidence) ={lk0}, hyper = ({hyper['aw']},{hyper['bw']},"
+                  f"{hyper['ah']},{hyper['bh']})")
+        ew = wh["ew"]
+        contains_unif = np.abs(ew.max(axis=0) - ew.min(axis=0)) < bundle["Tol"]  # :368-369
+        if contains_unif.sum() > 0:
+            cols = ",".join(str(c + 1) for c in np.nonzero(contains_unif)[0])
+            warnings.warn(f"Rank {rank} row/column {cols} constant.")
+            if bundle["unif_stop"]:
+                warnings.warn(f"Rank scan stopped for rank >= {rank}")
+                if irank == 0:
+                    raise RuntimeError("Rerun with lower ranks")                 # :375
+                break
+        rdat[irank] = lk0                                                        # :379
+        wdat[irank] = wh["ew"]; hdat[irank] = wh["eh"]
+        dwdat[irank] = np.sqrt(wh["dw"]); dhdat[irank] = np.sqrt(wh["dh"])       # :382-383
+        hyperp[irank] = hyper
+        nsteps[irank] = it
+    return {"rdat": rdat, "wdat": wdat, "hdat": hdat, "hyperp": hyperp, "nunif": nunif,
+            "dwdat": dwdat, "dhdat": dhdat, "nsteps": nsteps}
+
+
+def select_best(vb, ranks):
+    """Best run per rank by maximum log evidence; reference R/bayesian.R:265-299."""
+    res = VBResult()
+    cols = {k: [] for k in ("rank", "lml", "aw", "bw", "ah", "bh", "nunif")}
+    for k, rank in enumerate(ranks):
+        rmax, imax = -math.inf, None
+        for i, run in enumerate(vb):
+            if run["rdat"][k] > rmax:                                            # :271
+                imax, rmax = i, run["rdat"][k]
+        if rmax == -math.inf:                                                    # :276
+            continue
+        run = vb[imax]
+        res.ranks.append(rank)
+        res.basis.append(run["wdat"][k]); res.coeff.append(run["hdat"][k])
+        res.dbasis.append(run["dwdat"][k]); res.dcoeff.append(run["dhdat"][k])
+        res.nsteps.append(run["nsteps"][k])
+        hy = run["hyperp"][k]
+        for key, val in (("rank", rank), ("lml", rmax), ("aw", hy["aw"]), ("bw", hy["bw"]),
+                         ("ah", hy["ah"]), ("bh", hy["bh"]), ("nunif", run["nunif"][k])):
+            cols[key].append(val)
+    res.measure = cols
+    return res
+
+
+def make_bundle(mat, ranks, nrun, verbose, initializer, Itmax, hyper_update, gamma_a, gamma_b, Tol,
+                hyper_update_n0, hyper_update_dn, fudge, unif_stop, seed, device):
+    """Argument handling and guards of reference R/bayesian.R:238-259."""
+    if fudge is None:
+        fudge = EPS                                                              # :238
+    if initializer in ("svd", "svd2") and nrun > 1:
+        raise ValueError("SVD initializer does not require nrun > 1")            # :241-242
+    X = mat if isinstance(mat, CountMatrix) else CountMatrix(mat)
+    nullr, nullc = X.empty_counts()                                              # :244-245
+    if nullr > 0:
+        raise ValueError("Input matrix contains empty rows")
+    if nullc > 0:
+        raise ValueError("Input matrix contains empty columns")
+    ranks = [int(r) for r in np.atleast_1d(ranks) if r <= X.shape[1]]            # :249
+    return {"mat": X, "raw": None if isinstance(mat, CountMatrix) else mat, "ranks": ranks, "verbose": verbose,
+            "gamma_a": gamma_a, "gamma_b": gamma_b, "initializer": initializer, "Itmax": Itmax, "fudge": fudge,
+            "hyper_update": list(hyper_update), "hyper_update_n0": hyper_update_n0,
+            "hyper_update_dn": hyper_update_dn, "Tol": Tol, "unif_stop": unif_stop, "nrun": nrun,
+            "seed": seed, "device": device}
+
+
+def vb_factorize(mat, ranks=2, nrun=1, verbose=2, progress_bar=True, initializer="random", Itmax=10000,
+                 hyper_update=(True, True, True, True), gamma_a=1, gamma_b=1, Tol=1e-5,
+                 hyper_update_n0=10, hyper_update_dn=1, connectivity=False, fudge=None, ncores=1,
+                 useC=True, unif_stop=True, seed=None, device=0):
+    """Bayesian NMF of a count matrix on the MI355X engine; reference R/bayesian.R:229-301.
+
+    ``mat`` is the genes x cells count matrix (dense, scipy sparse, or ``CountMatrix``).
+    ``connectivity`` (reference default TRUE) is post-processing outside this path and is
+    not computed; ``ncores`` / Rmpi is replaced by ``ccfindr_amd.parallel``; ``useC`` selects
+    nothing (the native engine is the only backend); ``progress_bar`` is unused, as in the
+    reference.  ``seed`` seeds the numpy Generator of the ``random`` initialiser.
+    """
+    del progress_bar, useC, ncores
+    if connectivity:
+        warnings.warn("connectivity/dispersion are outside the VB update path and are not computed")
+    bundle = make_bundle(mat, ranks, nrun, verbose, initializer, Itmax, hyper_update, gamma_a, gamma_b, Tol,
+                         hyper_update_n0, hyper_update_dn, fudge, unif_stop, seed, device)
+    vb = [vb_iterate(irun, bundle) for irun in range(1, nrun + 1)]               # :260-261
+    return select_best(vb, bundle["ranks"])

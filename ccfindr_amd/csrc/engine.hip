@@ -1,0 +1,617 @@
+// engine.hip -- the device-resident VB-NMF engine behind the C ABI of include/vbnmf.h.
+//
+// One step (reference src/vbnmf_update.cpp:33-90) is seven launches on one HIP stream:
+//   k_update(W)  k_reduce(W)  k_update(H)  k_sweep(both sides)  k_pack  k_reduce(H, evidence)  k_final
+// The sweep at the end of step t produces the sufficient statistics that step t+1 starts
+// from AND the data term of step t's evidence (see kernels.h), so X is streamed once per
+// step and side.  The packed reduce buffer [swsum | rowSum(eh) | scalars] is what a
+// cell-partitioned run all-reduces between step_local and step_finish.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+
+#include "common.h"
+#include "kernels.h"
+
+using namespace vbnmf;
+
+#define HIPCHECK(expr)                                                                                   \
+    do {                                                                                                 \
+        hipError_t _e = (expr);                                                                          \
+        if (_e != hipSuccess)                                                                            \
+            return fail(VBNMF_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+namespace {
+
+struct DeviceSide {
+    uint32_t *packed = nullptr, *widx = nullptr, *slice_major = nullptr;
+    double *wval = nullptr;
+    int32_t *slice_width = nullptr, *tile_block = nullptr;
+    int64_t *slice_off = nullptr, *tile_slice0 = nullptr;
+    double *part = nullptr;
+    int64_t n_major = 0, n_minor = 0, n_tiles = 0, n_slices = 0, n_slots = 0;
+    int32_t block_width = 0, n_blocks = 0;
+    bool wide = false;
+};
+
+template <typename T>
+int dev_alloc(T **p, size_t count)
+{
+    *p = nullptr;
+    if (count == 0) count = 1;
+    hipError_t e = hipMalloc((void **)p, count * sizeof(T));
+    if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); return fail(VBNMF_ERR_OOM, "out of device memory (%zu bytes)", count * sizeof(T)); }
+    if (e != hipSuccess) return fail(VBNMF_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(e));
+    return VBNMF_OK;
+}
+
+template <typename T>
+int dev_upload(T **p, const std::vector<T> &v)
+{
+    if (int rc = dev_alloc(p, v.size())) return rc;
+    if (!v.empty()) HIPCHECK(hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return VBNMF_OK;
+}
+
+}  // namespace
+
+struct vbnmf_engine {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int64_t n = 0, m = 0, m_global = 0, nnz = 0;
+    int r = 0, R = 0, NT = 0;
+    bool wide = false, partitioned = false;
+    double lgx = 0.0;
+    DeviceSide A, B;                  // A: lanes own genes ; B: lanes own cells
+    double *lw = nullptr, *llw = nullptr, *ew = nullptr, *dw = nullptr;
+    double *lh = nullptr, *llh = nullptr, *eh = nullptr, *dh = nullptr;
+    double *epart = nullptr;          // [A.n_slices + B.n_slices]
+    double *bpW = nullptr, *bpH = nullptr;
+    int64_t nbW = 0, nbH = 0;
+    double *outW = nullptr;           // [R+2]
+    double *red = nullptr;            // [n*R | R+4]
+    int64_t red_count = 0;
+    double *d_out = nullptr;          // [8]
+    double *h_out = nullptr;          // pinned [8]
+    size_t lds_bytes = 0;
+    bool has_state = false, stats_ready = false, step_pending = false, prime_pending = false;
+    bool timing = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool ev_recorded = false;
+    double sweep_ms = 0.0;
+    int64_t sweep_launches = 0;
+};
+
+namespace {
+
+void free_side(DeviceSide &S)
+{
+    (void)hipFree(S.packed); (void)hipFree(S.widx); (void)hipFree(S.wval); (void)hipFree(S.slice_major);
+    (void)hipFree(S.slice_width); (void)hipFree(S.tile_block); (void)hipFree(S.slice_off);
+    (void)hipFree(S.tile_slice0); (void)hipFree(S.part);
+    S = DeviceSide();
+}
+
+int upload_side(const Layout &L, int R, DeviceSide &S)
+{
+    S.n_major = L.n_major; S.n_minor = L.n_minor; S.n_tiles = L.n_tiles; S.n_slices = L.n_slices;
+    S.n_slots = L.n_slots; S.block_width = L.block_width; S.n_blocks = L.n_blocks; S.wide = L.wide;
+    if (L.wide) {
+        if (int rc = dev_upload(&S.widx, L.wide_idx)) return rc;
+        if (int rc = dev_upload(&S.wval, L.wide_val)) return rc;
+    } else {
+        if (int rc = dev_upload(&S.packed, L.packed)) return rc;
+    }
+    if (int rc = dev_upload(&S.slice_major, L.slice_major)) return rc;
+    if (int rc = dev_upload(&S.slice_width, L.slice_width)) return rc;
+    if (int rc = dev_upload(&S.slice_off, L.slice_off)) return rc;
+    if (int rc = dev_upload(&S.tile_block, L.tile_block)) return rc;
+    if (int rc = dev_upload(&S.tile_slice0, L.tile_slice0)) return rc;
+    if (int rc = dev_alloc(&S.part, (size_t)L.n_blocks * L.n_major * R)) return rc;
+    return VBNMF_OK;
+}
+
+SweepSide sweep_side(const vbnmf_engine *e, const DeviceSide &S, bool gene_side, double *epart)
+{
+    SweepSide P;
+    P.packed = S.packed; P.widx = S.widx; P.wval = S.wval;
+    P.slice_major = S.slice_major; P.slice_width = S.slice_width; P.slice_off = S.slice_off;
+    P.tile_block = S.tile_block; P.tile_slice0 = S.tile_slice0;
+    P.F = gene_side ? e->lw : e->lh;
+    P.llF = gene_side ? e->llw : e->llh;
+    P.G = gene_side ? e->lh : e->lw;
+    P.part = S.part; P.epart = epart;
+    P.n_major = S.n_major; P.n_minor = (int32_t)S.n_minor; P.block_width = S.block_width;
+    P.logterm = gene_side ? 1 : 0;
+    P.n_tiles = (int32_t)S.n_tiles;
+    return P;
+}
+
+// ---- dispatch over the padded rank (compile-time so factor rows live in registers) ----
+template <int R, bool WIDE, int NT>
+int launch_sweep_t(vbnmf_engine *e, const SweepSide &a, const SweepSide &b)
+{
+    static bool attr_set[16] = {false};
+    const void *fn = (const void *)k_sweep<R, WIDE, NT>;
+    if (e->device < 16 && !attr_set[e->device]) {
+        HIPCHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set[e->device] = true;
+    } else if (e->device >= 16) {
+        HIPCHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
+    const unsigned grid = (unsigned)(a.n_tiles + b.n_tiles);
+    hipLaunchKernelGGL((k_sweep<R, WIDE, NT>), dim3(grid), dim3(NT), e->lds_bytes, e->stream, a, b);
+    HIPCHECK(hipGetLastError());
+    return VBNMF_OK;
+}
+
+template <int R>
+int launch_sweep_r(vbnmf_engine *e, const SweepSide &a, const SweepSide &b)
+{
+    constexpr int NT = sweep_threads(R);
+    return e->wide ? launch_sweep_t<R, true, NT>(e, a, b) : launch_sweep_t<R, false, NT>(e, a, b);
+}
+
+#define VBNMF_FOR_EACH_R(X) \
+    X(2) X(4) X(6) X(8) X(10) X(12) X(14) X(16) X(18) X(20) X(22) X(24) X(26) X(28) X(30) X(32)
+
+int launch_sweep(vbnmf_engine *e)
+{
+    SweepSide a = sweep_side(e, e->A, true, e->epart);
+    SweepSide b = sweep_side(e, e->B, false, e->epart + e->A.n_slices);
+    if (e->timing) { HIPCHECK(hipEventRecord(e->ev0, e->stream)); }
+    int rc = VBNMF_ERR_BAD_ARG;
+    switch (e->R) {
+#define X(RR) case RR: rc = launch_sweep_r<RR>(e, a, b); break;
+        VBNMF_FOR_EACH_R(X)
+#undef X
+        default: return fail(VBNMF_ERR_BAD_ARG, "unsupported padded rank %d", e->R);
+    }
+    if (rc) return rc;
+    if (e->timing) { HIPCHECK(hipEventRecord(e->ev1, e->stream)); e->ev_recorded = true; }
+    return VBNMF_OK;
+}
+
+int launch_update(vbnmf_engine *e, bool gene_side, double a, double b, double fudge)
+{
+    const double lga = -std::lgamma(a) + a * std::log(a / b);     // reference :82 / :87
+    const double *acc = gene_side ? e->red : e->B.part;
+    const int nacc = gene_side ? 1 : e->B.n_blocks;
+    const int64_t nmaj = gene_side ? e->n : e->m;
+    const double *other = gene_side ? e->red + (size_t)e->n * e->R : e->outW;
+    double *l = gene_side ? e->lw : e->lh, *ll = gene_side ? e->llw : e->llh;
+    double *ev = gene_side ? e->ew : e->eh, *d = gene_side ? e->dw : e->dh;
+    double *bp = gene_side ? e->bpW : e->bpH;
+    const unsigned grid = (unsigned)(gene_side ? e->nbW : e->nbH);
+    switch (e->R) {
+#define X(RR) case RR: hipLaunchKernelGGL((k_update<RR>), dim3(grid), dim3(256), 0, e->stream, acc, nacc, nmaj, e->r, other, a, b, lga, fudge, l, ll, ev, d, bp); break;
+        VBNMF_FOR_EACH_R(X)
+#undef X
+        default: return fail(VBNMF_ERR_BAD_ARG, "unsupported padded rank %d", e->R);
+    }
+    HIPCHECK(hipGetLastError());
+    return VBNMF_OK;
+}
+
+int launch_prime(vbnmf_engine *e, bool gene_side)
+{
+    const int64_t nmaj = gene_side ? e->n : e->m;
+    const double *l = gene_side ? e->lw : e->lh;
+    double *ll = gene_side ? e->llw : e->llh;
+    const double *ev = gene_side ? nullptr : e->eh;
+    double *bp = gene_side ? e->bpW : e->bpH;
+    const unsigned grid = (unsigned)(gene_side ? e->nbW : e->nbH);
+    switch (e->R) {
+#define X(RR) case RR: hipLaunchKernelGGL((k_prime<RR>), dim3(grid), dim3(256), 0, e->stream, nmaj, e->r, l, ll, ev, bp); break;
+        VBNMF_FOR_EACH_R(X)
+#undef X
+        default: return fail(VBNMF_ERR_BAD_ARG, "unsupported padded rank %d", e->R);
+    }
+    HIPCHECK(hipGetLastError());
+    return VBNMF_OK;
+}
+
+int launch_final(vbnmf_engine *e)
+{
+    const double *tail = e->red + (size_t)e->n * e->R;
+    switch (e->R) {
+#define X(RR) case RR: hipLaunchKernelGGL((k_final<RR>), dim3(1), dim3(64), 0, e->stream, e->outW, tail, e->r, (double)e->n, (double)e->m_global, e->d_out); break;
+        VBNMF_FOR_EACH_R(X)
+#undef X
+        default: return fail(VBNMF_ERR_BAD_ARG, "unsupported padded rank %d", e->R);
+    }
+    HIPCHECK(hipGetLastError());
+    return VBNMF_OK;
+}
+
+// reduce the gene-side block partials into outW = [colSum(ew) | sum W-terms | sum log lw]
+int launch_reduce_w(vbnmf_engine *e)
+{
+    ReduceArgs a{};
+    a.src = e->bpW; a.count = e->nbW; a.stride = e->R + 2; a.ncols = e->R + 2; a.dst = e->outW;
+    hipLaunchKernelGGL(k_reduce, dim3(a.ncols), dim3(256), 0, e->stream, a);
+    HIPCHECK(hipGetLastError());
+    return VBNMF_OK;
+}
+
+// sweep output -> reduce buffer: swsum, then tail = [rowSum(eh) | sum H-terms | sum log lh | data term | lgx]
+int launch_pack(vbnmf_engine *e)
+{
+    const int64_t cnt = e->n * e->R;
+    hipLaunchKernelGGL(k_pack, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, e->stream, e->A.part, e->A.n_blocks, cnt, e->red);
+    HIPCHECK(hipGetLastError());
+    double *tail = e->red + cnt;
+    ReduceArgs a{};
+    a.src = e->bpH; a.count = e->nbH; a.stride = e->R + 2; a.ncols = e->R + 2; a.dst = tail;
+    a.vsrc = e->epart; a.vcount = e->A.n_slices + e->B.n_slices; a.vdst = tail + e->R + 2;
+    a.cdst = tail + e->R + 3; a.cval = e->lgx;
+    hipLaunchKernelGGL(k_reduce, dim3(a.ncols + 1), dim3(256), 0, e->stream, a);
+    HIPCHECK(hipGetLastError());
+    return VBNMF_OK;
+}
+
+int harvest_timing(vbnmf_engine *e)
+{
+    if (e->timing && e->ev_recorded) {
+        float ms = 0.f;
+        HIPCHECK(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+        e->sweep_ms += ms;
+        e->sweep_launches++;
+        e->ev_recorded = false;
+    }
+    return VBNMF_OK;
+}
+
+int use_device(const vbnmf_engine *e)
+{
+    HIPCHECK(hipSetDevice(e->device));
+    return VBNMF_OK;
+}
+
+int check_device(int device)
+{
+    int cnt = 0;
+    hipError_t err = hipGetDeviceCount(&cnt);
+    if (err != hipSuccess || cnt <= 0) {
+        (void)hipGetLastError();
+        return fail(VBNMF_ERR_NO_DEVICE, "no HIP device is available (%s); this library has no CPU fallback",
+                    err != hipSuccess ? hipGetErrorString(err) : "device count is 0");
+    }
+    if (device < 0 || device >= cnt) return fail(VBNMF_ERR_BAD_ARG, "device %d is outside [0, %d)", device, cnt);
+    hipDeviceProp_t prop;
+    HIPCHECK(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(VBNMF_ERR_NO_DEVICE, "device %d is %s; this library carries gfx950 (MI355X) code only", device, prop.gcnArchName);
+    return VBNMF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t vbnmf_device_count(void)
+{
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return cnt;
+}
+
+void vbnmf_engine_destroy(vbnmf_engine *e)
+{
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    free_side(e->A); free_side(e->B);
+    (void)hipFree(e->lw); (void)hipFree(e->llw); (void)hipFree(e->ew); (void)hipFree(e->dw);
+    (void)hipFree(e->lh); (void)hipFree(e->llh); (void)hipFree(e->eh); (void)hipFree(e->dh);
+    (void)hipFree(e->epart); (void)hipFree(e->bpW); (void)hipFree(e->bpH); (void)hipFree(e->outW);
+    (void)hipFree(e->red); (void)hipFree(e->d_out);
+    if (e->h_out) (void)hipHostFree(e->h_out);
+    if (e->ev0) (void)hipEventDestroy(e->ev0);
+    if (e->ev1) (void)hipEventDestroy(e->ev1);
+    if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int vbnmf_engine_create_part(const vbnmf_matrix *X, int64_t cb, int64_t ce, int64_t m_global, int32_t r,
+                             int32_t device, vbnmf_engine **out)
+{
+    if (!out) return fail(VBNMF_ERR_BAD_ARG, "out pointer is NULL");
+    *out = nullptr;
+    if (!X) return fail(VBNMF_ERR_BAD_ARG, "matrix handle is NULL");
+    if (r < 1 || r > VBNMF_MAX_RANK) return fail(VBNMF_ERR_BAD_ARG, "rank %d is outside [1, %d]", r, VBNMF_MAX_RANK);
+    if (cb < 0 || ce > X->M.m || cb >= ce) return fail(VBNMF_ERR_BAD_ARG, "column range [%lld, %lld) is outside the matrix", (long long)cb, (long long)ce);
+    if (m_global < ce - cb) return fail(VBNMF_ERR_BAD_ARG, "m_global is smaller than the partition");
+    if (int rc = check_device(device)) return rc;
+    HIPCHECK(hipSetDevice(device));
+
+    vbnmf_engine *e = new (std::nothrow) vbnmf_engine();
+    if (!e) return fail(VBNMF_ERR_OOM, "out of host memory");
+    e->device = device;
+    e->n = X->M.n; e->m = ce - cb; e->m_global = m_global;
+    e->r = r; e->R = padded_rank(r);
+    e->NT = sweep_threads(e->R);
+    e->wide = !X->M.counts_u16;
+    e->partitioned = (ce - cb) != m_global;
+    int rc = VBNMF_OK;
+    auto bail = [&](int code) { vbnmf_engine_destroy(e); return code; };
+
+    try {
+        for (int side = 0; side < 2 && !rc; side++) {
+            Layout L;
+            int64_t nmaj = side == 0 ? e->n : e->m, nmin = side == 0 ? e->m : e->n;
+            LayoutParams lp = default_layout_params(nmaj, nmin, e->R);
+            rc = build_layout(X->M, cb, ce, side, lp, L);
+            if (!rc) rc = upload_side(L, e->R, side == 0 ? e->A : e->B);
+            if (side == 0) e->nnz = L.nnz;
+        }
+    } catch (const std::bad_alloc &) {
+        rc = fail(VBNMF_ERR_OOM, "out of host memory building the tiled layout");
+    }
+    if (rc) return bail(rc);
+    e->lgx = (cb == 0 && ce == X->M.m) ? X->lgx : sum_lgamma_x1(X->M, cb, ce);
+    e->lds_bytes = (size_t)std::max(e->A.block_width, e->B.block_width) * e->R * sizeof(double);
+
+    const size_t nR = (size_t)e->n * e->R, mR = (size_t)e->m * e->R;
+    const int RB = 256 / e->R;
+    e->nbW = (e->n + RB - 1) / RB;
+    e->nbH = (e->m + RB - 1) / RB;
+    e->red_count = (int64_t)nR + e->R + 4;
+    if ((rc = dev_alloc(&e->lw, nR)) || (rc = dev_alloc(&e->llw, nR)) || (rc = dev_alloc(&e->ew, nR)) || (rc = dev_alloc(&e->dw, nR)) ||
+        (rc = dev_alloc(&e->lh, mR)) || (rc = dev_alloc(&e->llh, mR)) || (rc = dev_alloc(&e->eh, mR)) || (rc = dev_alloc(&e->dh, mR)) ||
+        (rc = dev_alloc(&e->epart, (size_t)(e->A.n_slices + e->B.n_slices))) ||
+        (rc = dev_alloc(&e->bpW, (size_t)e->nbW * (e->R + 2))) || (rc = dev_alloc(&e->bpH, (size_t)e->nbH * (e->R + 2))) ||
+        (rc = dev_alloc(&e->outW, (size_t)e->R + 2)) || (rc = dev_alloc(&e->red, (size_t)e->red_count)) ||
+        (rc = dev_alloc(&e->d_out, 8)))
+        return bail(rc);
+    hipError_t he;
+    if ((he = hipHostMalloc((void **)&e->h_out, 8 * sizeof(double))) != hipSuccess ||
+        (he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (he = hipEventCreate(&e->ev0)) != hipSuccess || (he = hipEventCreate(&e->ev1)) != hipSuccess)
+        return bail(fail(VBNMF_ERR_HIP, "engine setup failed: %s", hipGetErrorString(he)));
+    e->own_stream = true;
+    if ((he = hipMemset(e->ew, 0, nR * sizeof(double))) != hipSuccess || (he = hipMemset(e->dw, 0, nR * sizeof(double))) != hipSuccess ||
+        (he = hipMemset(e->dh, 0, mR * sizeof(double))) != hipSuccess || (he = hipMemset(e->outW, 0, (e->R + 2) * sizeof(double))) != hipSuccess)
+        return bail(fail(VBNMF_ERR_HIP, "hipMemset failed: %s", hipGetErrorString(he)));
+    *out = e;
+    return VBNMF_OK;
+}
+
+int vbnmf_engine_create(const vbnmf_matrix *X, int32_t r, int32_t device, vbnmf_engine **out)
+{
+    if (!X) { if (out) *out = nullptr; return fail(VBNMF_ERR_BAD_ARG, "matrix handle is NULL"); }
+    return vbnmf_engine_create_part(X, 0, X->M.m, X->M.m, r, device, out);
+}
+
+int vbnmf_engine_dims(const vbnmf_engine *e, int64_t *n, int64_t *m_local, int32_t *r)
+{
+    if (!e) return fail(VBNMF_ERR_BAD_ARG, "engine handle is NULL");
+    if (n) *n = e->n;
+    if (m_local) *m_local = e->m;
+    if (r) *r = e->r;
+    return VBNMF_OK;
+}
+
+int vbnmf_engine_get_stream(vbnmf_engine *e, void **stream)
+{
+    if (!e || !stream) return fail(VBNMF_ERR_BAD_ARG, "NULL argument");
+    *stream = (void *)e->stream;
+    return VBNMF_OK;
+}
+
+int vbnmf_engine_set_stream(vbnmf_engine *e, void *stream)
+{
+    if (!e) return fail(VBNMF_ERR_BAD_ARG, "engine handle is NULL");
+    if (int rc = use_device(e)) return rc;
+    HIPCHECK(hipStreamSynchronize(e->stream));
+    if (e->own_stream) { (void)hipStreamDestroy(e->stream); e->own_stream = false; }
+    e->stream = (hipStream_t)stream;
+    return VBNMF_OK;
+}
+
+// column-major n x r (R matrix) -> device [n][R]; or r x m column-major (already index-major) -> [m][R]
+static void to_index_major(const double *src, int64_t nmaj, int r, int R, bool src_is_major_contiguous, std::vector<double> &dst)
+{
+    dst.assign((size_t)nmaj * R, 0.0);
+    parallel_for(nmaj, [&](int64_t b, int64_t e, int) {
+        for (int64_t M = b; M < e; M++)
+            for (int k = 0; k < r; k++)
+                dst[(size_t)M * R + k] = src_is_major_contiguous ? src[(size_t)M * r + k] : src[M + (size_t)k * nmaj];
+    });
+}
+
+static void from_index_major(const std::vector<double> &src, int64_t nmaj, int r, int R, bool dst_is_major_contiguous, double *dst)
+{
+    parallel_for(nmaj, [&](int64_t b, int64_t e, int) {
+        for (int64_t M = b; M < e; M++)
+            for (int k = 0; k < r; k++) {
+                double v = src[(size_t)M * R + k];
+                if (dst_is_major_contiguous) dst[(size_t)M * r + k] = v; else dst[M + (size_t)k * nmaj] = v;
+            }
+    });
+}
+
+int vbnmf_engine_set_state(vbnmf_engine *e, const double *lw, const double *lh, const double *eh)
+{
+    if (!e || !lw || !lh || !eh) return fail(VBNMF_ERR_BAD_ARG, "NULL argument");
+    if (int rc = use_device(e)) return rc;
+    e->has_state = false; e->stats_ready = false; e->step_pending = false; e->prime_pending = false;
+    try {
+        std::vector<double> tmp;
+        to_index_major(lw, e->n, e->r, e->R, false, tmp);
+        HIPCHECK(hipMemcpyAsync(e->lw, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
+        HIPCHECK(hipStreamSynchronize(e->stream));
+        to_index_major(lh, e->m, e->r, e->R, true, tmp);
+        HIPCHECK(hipMemcpyAsync(e->lh, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
+        HIPCHECK(hipStreamSynchronize(e->stream));
+        to_index_major(eh, e->m, e->r, e->R, true, tmp);
+        HIPCHECK(hipMemcpyAsync(e->eh, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
+        HIPCHECK(hipStreamSynchronize(e->stream));
+    } catch (const std::bad_alloc &) {
+        return fail(VBNMF_ERR_OOM, "out of host memory staging the state");
+    }
+    e->has_state = true;
+    // statistics of the loaded state: rowSum(eh), then the sweep (its evidence partials are not used)
+    if (int rc = launch_prime(e, true)) return rc;
+    if (int rc = launch_prime(e, false)) return rc;
+    if (int rc = launch_sweep(e)) return rc;
+    if (int rc = launch_pack(e)) return rc;
+    e->prime_pending = true;
+    if (!e->partitioned) return vbnmf_engine_state_finish(e);
+    return VBNMF_OK;
+}
+
+int vbnmf_engine_state_finish(vbnmf_engine *e)
+{
+    if (!e) return fail(VBNMF_ERR_BAD_ARG, "engine handle is NULL");
+    if (!e->prime_pending) return fail(VBNMF_ERR_STATE, "state_finish without a pending set_state");
+    if (int rc = use_device(e)) return rc;
+    HIPCHECK(hipStreamSynchronize(e->stream));
+    if (int rc = harvest_timing(e)) return rc;
+    e->sweep_ms = 0.0; e->sweep_launches = 0;        // the priming sweep is not a step
+    e->prime_pending = false;
+    e->stats_ready = true;
+    return VBNMF_OK;
+}
+
+int vbnmf_engine_step_local(vbnmf_engine *e, double aw, double bw, double ah, double bh, double fudge)
+{
+    if (!e) return fail(VBNMF_ERR_BAD_ARG, "engine handle is NULL");
+    if (!e->has_state || !e->stats_ready) return fail(VBNMF_ERR_STATE, "step before set_state (or before state_finish on a partitioned engine)");
+    if (e->step_pending) return fail(VBNMF_ERR_STATE, "step_local called twice without step_finish");
+    if (int rc = use_device(e)) return rc;
+    if (int rc = launch_update(e, true, aw, bw, fudge)) return rc;
+    if (int rc = launch_reduce_w(e)) return rc;
+    if (int rc = launch_update(e, false, ah, bh, fudge)) return rc;
+    if (int rc = launch_sweep(e)) return rc;
+    if (int rc = launch_pack(e)) return rc;
+    e->step_pending = true;
+    return VBNMF_OK;
+}
+
+int vbnmf_engine_reduce_buffer(vbnmf_engine *e, void **device_ptr, int64_t *count)
+{
+    if (!e) return fail(VBNMF_ERR_BAD_ARG, "engine handle is NULL");
+    if (device_ptr) *device_ptr = e->red;
+    if (count) *count = e->red_count;
+    return VBNMF_OK;
+}
+
+int vbnmf_engine_step_finish(vbnmf_engine *e, double *lkh, double *stats)
+{
+    if (!e) return fail(VBNMF_ERR_BAD_ARG, "engine handle is NULL");
+    if (!e->step_pending) return fail(VBNMF_ERR_STATE, "step_finish without step_local");
+    if (int rc = use_device(e)) return rc;
+    if (int rc = launch_final(e)) return rc;
+    HIPCHECK(hipMemcpyAsync(e->h_out, e->d_out, 5 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    HIPCHECK(hipStreamSynchronize(e->stream));
+    e->step_pending = false;
+    if (int rc = harvest_timing(e)) return rc;
+    if (lkh) *lkh = e->h_out[0];
+    if (stats) for (int q = 0; q < 4; q++) stats[q] = e->h_out[1 + q];
+    return VBNMF_OK;
+}
+
+int vbnmf_engine_step(vbnmf_engine *e, double aw, double bw, double ah, double bh, double fudge, double *lkh, double *stats)
+{
+    if (e && e->partitioned) return fail(VBNMF_ERR_STATE, "a partitioned engine needs step_local / all-reduce / step_finish");
+    if (int rc = vbnmf_engine_step_local(e, aw, bw, ah, bh, fudge)) return rc;
+    return vbnmf_engine_step_finish(e, lkh, stats);
+}
+
+int vbnmf_engine_get_state(vbnmf_engine *e, double *lw, double *lh, double *ew, double *eh, double *dw, double *dh)
+{
+    if (!e) return fail(VBNMF_ERR_BAD_ARG, "engine handle is NULL");
+    if (!e->has_state) return fail(VBNMF_ERR_STATE, "get_state before set_state");
+    if (int rc = use_device(e)) return rc;
+    HIPCHECK(hipStreamSynchronize(e->stream));
+    try {
+        std::vector<double> tmp;
+        struct Item { double *dst; const double *src; bool gene; };
+        const Item items[6] = {{lw, e->lw, true}, {ew, e->ew, true}, {dw, e->dw, true},
+                               {lh, e->lh, false}, {eh, e->eh, false}, {dh, e->dh, false}};
+        for (const Item &it : items) {
+            if (!it.dst) continue;
+            const int64_t nmaj = it.gene ? e->n : e->m;
+            tmp.resize((size_t)nmaj * e->R);
+            HIPCHECK(hipMemcpy(tmp.data(), it.src, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+            from_index_major(tmp, nmaj, e->r, e->R, !it.gene, it.dst);
+        }
+    } catch (const std::bad_alloc &) {
+        return fail(VBNMF_ERR_OOM, "out of host memory staging the state");
+    }
+    return VBNMF_OK;
+}
+
+int vbnmf_engine_timing_enable(vbnmf_engine *e, int32_t on)
+{
+    if (!e) return fail(VBNMF_ERR_BAD_ARG, "engine handle is NULL");
+    e->timing = on != 0;
+    e->sweep_ms = 0.0; e->sweep_launches = 0; e->ev_recorded = false;
+    return VBNMF_OK;
+}
+
+int vbnmf_engine_timing_get(vbnmf_engine *e, double *sweep_ms, int64_t *sweep_launches)
+{
+    if (!e) return fail(VBNMF_ERR_BAD_ARG, "engine handle is NULL");
+    if (sweep_ms) *sweep_ms = e->sweep_ms;
+    if (sweep_launches) *sweep_launches = e->sweep_launches;
+    e->sweep_ms = 0.0; e->sweep_launches = 0;
+    return VBNMF_OK;
+}
+
+int vbnmf_engine_layout_info(const vbnmf_engine *e, int64_t *nnz, int64_t *slots_gene, int64_t *slots_cell,
+                             int64_t *stream_bytes, int64_t *tiles_gene, int64_t *tiles_cell)
+{
+    if (!e) return fail(VBNMF_ERR_BAD_ARG, "engine handle is NULL");
+    if (nnz) *nnz = e->nnz;
+    if (slots_gene) *slots_gene = e->A.n_slots;
+    if (slots_cell) *slots_cell = e->B.n_slots;
+    if (stream_bytes) *stream_bytes = (e->A.n_slots + e->B.n_slots) * (int64_t)(e->wide ? 12 : 4);
+    if (tiles_gene) *tiles_gene = e->A.n_tiles;
+    if (tiles_cell) *tiles_cell = e->B.n_tiles;
+    return VBNMF_OK;
+}
+
+// ---------------------------------------------------------------- stateless forms
+static int update_once(vbnmf_matrix *X, int32_t r, const double *lw_in, const double *lh_in, const double *eh_in,
+                       double aw, double bw, double ah, double bh, double fudge,
+                       double *lw, double *lh, double *ew, double *eh, double *dw, double *dh, double *lkh)
+{
+    vbnmf_engine *e = nullptr;
+    int rc = vbnmf_engine_create(X, r, 0, &e);
+    if (!rc) rc = vbnmf_engine_set_state(e, lw_in, lh_in, eh_in);
+    if (!rc) rc = vbnmf_engine_step(e, aw, bw, ah, bh, fudge, lkh, nullptr);
+    if (!rc) rc = vbnmf_engine_get_state(e, lw, lh, ew, eh, dw, dh);
+    vbnmf_engine_destroy(e);
+    vbnmf_matrix_destroy(X);
+    return rc;
+}
+
+int vbnmf_update_dense(int64_t n, int64_t m, int32_t r, const double *X, const double *lw_in, const double *lh_in,
+                       const double *eh_in, double aw, double bw, double ah, double bh, double fudge,
+                       double *lw, double *lh, double *ew, double *eh, double *dw, double *dh, double *lkh)
+{
+    if (!lw_in || !lh_in || !eh_in) return fail(VBNMF_ERR_BAD_ARG, "a wh member is NULL");
+    vbnmf_matrix *M = nullptr;
+    if (int rc = vbnmf_matrix_from_dense(n, m, X, &M)) return rc;
+    return update_once(M, r, lw_in, lh_in, eh_in, aw, bw, ah, bh, fudge, lw, lh, ew, eh, dw, dh, lkh);
+}
+
+int vbnmf_update_csc(int64_t n, int64_t m, int32_t r, const int32_t *p, const int32_t *i, const double *x,
+                     const double *lw_in, const double *lh_in, const double *eh_in,
+                     double aw, double bw, double ah, double bh, double fudge,
+                     double *lw, double *lh, double *ew, double *eh, double *dw, double *dh, double *lkh)
+{
+    if (!lw_in || !lh_in || !eh_in) return fail(VBNMF_ERR_BAD_ARG, "a wh member is NULL");
+    vbnmf_matrix *M = nullptr;
+    if (int rc = vbnmf_matrix_from_csc(n, m, p, i, x, &M)) return rc;
+    return update_once(M, r, lw_in, lh_in, eh_in, aw, bw, ah, bh, fudge, lw, lh, ew, eh, dw, dh, lkh);
+}
+
+}  // extern "C"

@@ -1,0 +1,538 @@
+// host.cpp -- host side of libvbnmf_hip.so: error plumbing, ingestion of X into the
+// canonical CSC copy, and the builder of the tiled device layout.  No device code here.
+//
+// Reference behaviour this replaces: vb_iterate hands `as.matrix(bundle$mat)` to the
+// native step on EVERY iteration (reference R/bayesian.R:339) and Rcpp copies it again
+// into an Eigen::MatrixXd (reference src/RcppExports.cpp:15).  Here X is ingested once.
+#include "common.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <numeric>
+
+namespace vbnmf {
+
+// ------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+
+void set_error(const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+const char *last_error_cstr() { return g_err.c_str(); }
+
+// ------------------------------------------------------------------ threads
+int host_threads()
+{
+    static int n = [] {
+        if (const char *s = getenv("VBNMF_HOST_THREADS")) {
+            int v = atoi(s);
+            if (v > 0) return v;
+        }
+        unsigned hc = std::thread::hardware_concurrency();
+        int v = hc ? (int)hc : 1;
+        return std::min(v, 32);
+    }();
+    return n;
+}
+
+void parallel_for(int64_t count, const std::function<void(int64_t, int64_t, int)> &fn, int max_threads)
+{
+    if (count <= 0) return;
+    int nt = max_threads > 0 ? max_threads : host_threads();
+    if ((int64_t)nt > count) nt = (int)count;
+    if (nt <= 1) { fn(0, count, 0); return; }
+    std::vector<std::thread> th;
+    th.reserve(nt);
+    for (int t = 0; t < nt; t++) {
+        int64_t b = count * t / nt, e = count * (t + 1) / nt;
+        th.emplace_back([&fn, b, e, t] { fn(b, e, t); });
+    }
+    for (auto &x : th) x.join();
+}
+
+// ------------------------------------------------------------------ ingestion
+static void finish_matrix(Matrix &X)
+{
+    X.nnz = X.colptr[X.m];
+    bool ok = true;
+    for (int64_t e = 0; e < X.nnz && ok; e++) {
+        double v = X.val[e];
+        ok = (v >= 1.0 && v <= 65535.0 && v == std::floor(v));
+    }
+    X.counts_u16 = ok;
+}
+
+static int matrix_from_dense(int64_t n, int64_t m, const double *A, Matrix &X)
+{
+    X.n = n; X.m = m;
+    X.colptr.assign(m + 1, 0);
+    parallel_for(m, [&](int64_t b, int64_t e, int) {
+        for (int64_t j = b; j < e; j++) {
+            const double *c = A + (size_t)j * n;
+            int64_t k = 0;
+            for (int64_t i = 0; i < n; i++) k += (c[i] != 0.0);
+            X.colptr[j + 1] = k;
+        }
+    });
+    for (int64_t j = 0; j < m; j++) X.colptr[j + 1] += X.colptr[j];
+    int64_t nnz = X.colptr[m];
+    X.row.resize(nnz);
+    X.val.resize(nnz);
+    parallel_for(m, [&](int64_t b, int64_t e, int) {
+        for (int64_t j = b; j < e; j++) {
+            const double *c = A + (size_t)j * n;
+            int64_t o = X.colptr[j];
+            for (int64_t i = 0; i < n; i++)
+                if (c[i] != 0.0) { X.row[o] = (int32_t)i; X.val[o] = c[i]; o++; }
+        }
+    });
+    finish_matrix(X);
+    return VBNMF_OK;
+}
+
+// Compressed input with `nouter` outer vectors of inner indices < ninner.  Produces the
+// canonical form in the same orientation (inner ascending, duplicates summed, zeros dropped).
+static int canonicalise(int64_t nouter, int64_t ninner, const int32_t *p, const int32_t *idx, const double *x,
+                        std::vector<int64_t> &optr, std::vector<int32_t> &oidx, std::vector<double> &oval)
+{
+    if (p[0] != 0) return fail(VBNMF_ERR_BAD_ARG, "pointer array must start at 0");
+    for (int64_t j = 0; j < nouter; j++)
+        if (p[j + 1] < p[j]) return fail(VBNMF_ERR_BAD_ARG, "pointer array is not non-decreasing at %lld", (long long)j);
+    int64_t nin = p[nouter];
+    for (int64_t e = 0; e < nin; e++)
+        if (idx[e] < 0 || idx[e] >= ninner)
+            return fail(VBNMF_ERR_BAD_ARG, "index %d at position %lld is outside [0, %lld)", idx[e], (long long)e, (long long)ninner);
+    optr.assign(nouter + 1, 0);
+    std::vector<int64_t> kept(nouter, 0);
+    // pass 1: per outer vector, sort a scratch copy and count surviving entries
+    std::vector<int32_t> sidx(nin);
+    std::vector<double> sval(nin);
+    parallel_for(nouter, [&](int64_t b, int64_t e, int) {
+        std::vector<std::pair<int32_t, double>> tmp;
+        for (int64_t j = b; j < e; j++) {
+            int64_t s = p[j], t = p[j + 1];
+            bool sorted = true;
+            for (int64_t q = s + 1; q < t; q++)
+                if (idx[q] <= idx[q - 1]) { sorted = false; break; }
+            int64_t o = s;
+            if (sorted) {
+                for (int64_t q = s; q < t; q++)
+                    if (x[q] != 0.0) { sidx[o] = idx[q]; sval[o] = x[q]; o++; }
+            } else {
+                tmp.clear();
+                for (int64_t q = s; q < t; q++) tmp.emplace_back(idx[q], x[q]);
+                std::stable_sort(tmp.begin(), tmp.end(),
+                                 [](const std::pair<int32_t, double> &a, const std::pair<int32_t, double> &c) { return a.first < c.first; });
+                size_t q = 0;
+                while (q < tmp.size()) {
+                    int32_t id = tmp[q].first;
+                    double v = 0.0;
+                    while (q < tmp.size() && tmp[q].first == id) { v += tmp[q].second; q++; }
+                    if (v != 0.0) { sidx[o] = id; sval[o] = v; o++; }
+                }
+            }
+            kept[j] = o - s;
+        }
+    });
+    for (int64_t j = 0; j < nouter; j++) optr[j + 1] = optr[j] + kept[j];
+    oidx.resize(optr[nouter]);
+    oval.resize(optr[nouter]);
+    parallel_for(nouter, [&](int64_t b, int64_t e, int) {
+        for (int64_t j = b; j < e; j++) {
+            int64_t s = p[j], o = optr[j];
+            for (int64_t q = 0; q < kept[j]; q++) { oidx[o + q] = sidx[s + q]; oval[o + q] = sval[s + q]; }
+        }
+    });
+    return VBNMF_OK;
+}
+
+static int matrix_from_csc(int64_t n, int64_t m, const int32_t *p, const int32_t *i, const double *x, Matrix &X)
+{
+    X.n = n; X.m = m;
+    int rc = canonicalise(m, n, p, i, x, X.colptr, X.row, X.val);
+    if (rc) return rc;
+    finish_matrix(X);
+    return VBNMF_OK;
+}
+
+// Transpose a canonical compressed matrix (nouter x ninner) into the other orientation.
+static void transpose_compressed(int64_t nouter, int64_t ninner, const int64_t *ptr, const int32_t *idx, const double *val,
+                                 int32_t idx_offset, std::vector<int64_t> &tptr, std::vector<int32_t> &tidx, std::vector<double> &tval)
+{
+    tptr.assign(ninner + 1, 0);
+    int64_t s = ptr[0], t = ptr[nouter];
+    for (int64_t e = s; e < t; e++) tptr[idx[e] + 1]++;
+    for (int64_t i = 0; i < ninner; i++) tptr[i + 1] += tptr[i];
+    tidx.resize(t - s);
+    tval.resize(t - s);
+    std::vector<int64_t> cur(tptr.begin(), tptr.end() - 1);
+    for (int64_t j = 0; j < nouter; j++)
+        for (int64_t e = ptr[j]; e < ptr[j + 1]; e++) {
+            int64_t o = cur[idx[e]]++;
+            tidx[o] = (int32_t)(j - idx_offset);
+            tval[o] = val[e];
+        }
+}
+
+static int matrix_from_csr(int64_t n, int64_t m, const int32_t *p, const int32_t *j, const double *x, Matrix &X)
+{
+    std::vector<int64_t> rptr;
+    std::vector<int32_t> ridx;
+    std::vector<double> rval;
+    int rc = canonicalise(n, m, p, j, x, rptr, ridx, rval);
+    if (rc) return rc;
+    X.n = n; X.m = m;
+    transpose_compressed(n, m, rptr.data(), ridx.data(), rval.data(), 0, X.colptr, X.row, X.val);
+    finish_matrix(X);
+    return VBNMF_OK;
+}
+
+// sum_ij lgamma(X_ij + 1) over stored entries (absent entries give lgamma(1) = 0): the
+// iteration-invariant part of reference src/vbnmf_update.cpp:80-81.  Per-column sums are
+// formed independently and then added in column order, so the value does not depend on the
+// host thread count.
+double sum_lgamma_x1(const Matrix &X, int64_t cb, int64_t ce)
+{
+    std::vector<double> table;
+    if (X.counts_u16) {
+        double mx = 0;
+        for (int64_t e = X.colptr[cb]; e < X.colptr[ce]; e++) mx = std::max(mx, X.val[e]);
+        table.resize((size_t)mx + 1);
+        for (size_t c = 0; c < table.size(); c++) table[c] = std::lgamma((double)c + 1.0);
+    }
+    std::vector<double> colsum(ce - cb, 0.0);
+    parallel_for(ce - cb, [&](int64_t b, int64_t e, int) {
+        for (int64_t j = b; j < e; j++) {
+            double s = 0.0;
+            for (int64_t q = X.colptr[cb + j]; q < X.colptr[cb + j + 1]; q++)
+                s += X.counts_u16 ? table[(size_t)X.val[q]] : std::lgamma(X.val[q] + 1.0);
+            colsum[j] = s;
+        }
+    });
+    double s = 0.0;
+    for (double v : colsum) s += v;
+    return s;
+}
+
+// ------------------------------------------------------------------ layout
+static int env_int(const char *name, int dflt)
+{
+    const char *s = getenv(name);
+    if (!s || !*s) return dflt;
+    return atoi(s);
+}
+
+LayoutParams default_layout_params(int64_t n_major, int64_t n_minor, int R)
+{
+    (void)n_major;
+    LayoutParams lp;
+    // One minor block of the gathered factor must fit the workgroup's LDS: block_width * R * 8 bytes.
+    int lds_kb = env_int("VBNMF_LDS_KB", 160);
+    if (lds_kb < 8) lds_kb = 8;
+    if (lds_kb > 160) lds_kb = 160;
+    int64_t cmax = (int64_t)lds_kb * 1024 / ((int64_t)R * 8);
+    cmax &= ~(int64_t)7;
+    if (cmax > 65528) cmax = 65528;            // local minor index is 16 bits
+    if (cmax < 8) cmax = 8;
+    int64_t nb = (n_minor + cmax - 1) / cmax;
+    int64_t c = (n_minor + nb - 1) / nb;       // equal-width blocks instead of a short last one
+    c = (c + 7) & ~(int64_t)7;
+    if (c > cmax) c = cmax;
+    lp.block_width = (int32_t)c;
+    int chunk = env_int("VBNMF_CHUNK", 0);
+    if (chunk <= 0) chunk = sweep_threads(R);          // one slice per wave of the sweep workgroup
+    chunk = (chunk + 63) & ~63;
+    lp.chunk = chunk;
+    return lp;
+}
+
+int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const LayoutParams &lp, Layout &L)
+{
+    if (cb < 0 || ce > X.m || cb >= ce) return fail(VBNMF_ERR_BAD_ARG, "column range [%lld, %lld) is outside the matrix", (long long)cb, (long long)ce);
+    if (lp.block_width <= 0 || lp.block_width > 65536 || lp.chunk <= 0 || lp.chunk % kLanes)
+        return fail(VBNMF_ERR_BAD_ARG, "bad layout parameters");
+
+    // major-compressed view of X[:, cb:ce)
+    std::vector<int64_t> tptr;
+    std::vector<int32_t> tidx;
+    std::vector<double> tval;
+    const int64_t *ptr;
+    const int32_t *idx;
+    const double *val;
+    int64_t base;                 // ptr values are absolute positions into idx/val minus `base`
+    if (side == 1) {
+        L.n_major = ce - cb; L.n_minor = X.n;
+        ptr = X.colptr.data() + cb; idx = X.row.data(); val = X.val.data(); base = 0;
+    } else {
+        L.n_major = X.n; L.n_minor = ce - cb;
+        transpose_compressed(ce - cb, X.n, X.colptr.data() + cb, X.row.data(), X.val.data(), 0, tptr, tidx, tval);
+        // transpose_compressed numbers the outer vectors from 0, i.e. local cell ids already
+        ptr = tptr.data(); idx = tidx.data(); val = tval.data(); base = 0;
+        (void)base;
+    }
+    L.side = side;
+    L.wide = !X.counts_u16;
+    L.block_width = lp.block_width;
+    L.chunk = lp.chunk;
+    const int64_t nmaj = L.n_major;
+    const int32_t C = L.block_width;
+    const int32_t nblk = (int32_t)((L.n_minor + C - 1) / C);
+    const int64_t nchunk = (nmaj + L.chunk - 1) / L.chunk;
+    L.n_blocks = nblk;
+    L.n_tiles = nchunk * nblk;
+    L.nnz = ptr[nmaj] - ptr[0];
+
+    // bpos[major][b] = position of the major's first entry whose minor is in block >= b
+    std::vector<int64_t> bpos((size_t)nmaj * (nblk + 1));
+    parallel_for(nmaj, [&](int64_t b, int64_t e, int) {
+        for (int64_t M = b; M < e; M++) {
+            int64_t q = ptr[M], t = ptr[M + 1];
+            int64_t *bp = &bpos[(size_t)M * (nblk + 1)];
+            for (int32_t blk = 0; blk <= nblk; blk++) {
+                int64_t lim = (int64_t)blk * C;
+                while (q < t && idx[q] < lim) q++;
+                bp[blk] = q;
+            }
+        }
+    });
+
+    // per tile: majors sorted by their entry count in the tile (descending, ties by id), cut in slices of 64
+    struct TileTmp { std::vector<uint32_t> lanes; std::vector<int32_t> widths; int64_t slots = 0; };
+    std::vector<TileTmp> tmp(L.n_tiles);
+    parallel_for(L.n_tiles, [&](int64_t b, int64_t e, int) {
+        std::vector<std::pair<int64_t, uint32_t>> ord;
+        for (int64_t t = b; t < e; t++) {
+            int64_t c = t / nblk;
+            int32_t blk = (int32_t)(t % nblk);
+            int64_t m0 = c * L.chunk, m1 = std::min(nmaj, m0 + L.chunk);
+            ord.clear();
+            for (int64_t M = m0; M < m1; M++) {
+                const int64_t *bp = &bpos[(size_t)M * (nblk + 1)];
+                ord.emplace_back(bp[blk + 1] - bp[blk], (uint32_t)M);
+            }
+            std::sort(ord.begin(), ord.end(), [](const std::pair<int64_t, uint32_t> &a, const std::pair<int64_t, uint32_t> &c2) {
+                return a.first != c2.first ? a.first > c2.first : a.second < c2.second;
+            });
+            TileTmp &T = tmp[t];
+            int64_t nsl = ((m1 - m0) + kLanes - 1) / kLanes;
+            T.lanes.assign(nsl * kLanes, kIdleLane);
+            T.widths.assign(nsl, 0);
+            for (size_t q = 0; q < ord.size(); q++) T.lanes[q] = ord[q].second;
+            for (int64_t s = 0; s < nsl; s++) {
+                int64_t w = ord[s * kLanes].first;            // sorted: the slice's first lane is its longest
+                w = (w + kUnroll - 1) / kUnroll * kUnroll;
+                T.widths[s] = (int32_t)w;
+                T.slots += w * kLanes;
+            }
+        }
+    });
+
+    // heaviest tiles first (the dispatcher hands workgroups out in index order)
+    std::vector<int64_t> order(L.n_tiles);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t c) { return tmp[a].slots > tmp[c].slots; });
+
+    L.tile_block.resize(L.n_tiles);
+    L.tile_slice0.assign(L.n_tiles + 1, 0);
+    for (int64_t o = 0; o < L.n_tiles; o++) {
+        int64_t t = order[o];
+        L.tile_block[o] = (int32_t)(t % nblk);
+        L.tile_slice0[o + 1] = L.tile_slice0[o] + (int64_t)tmp[t].widths.size();
+    }
+    L.n_slices = L.tile_slice0[L.n_tiles];
+    L.slice_major.resize((size_t)L.n_slices * kLanes);
+    L.slice_width.resize(L.n_slices);
+    L.slice_off.resize(L.n_slices);
+    int64_t off = 0;
+    for (int64_t o = 0; o < L.n_tiles; o++) {
+        const TileTmp &T = tmp[order[o]];
+        int64_t s0 = L.tile_slice0[o];
+        for (size_t s = 0; s < T.widths.size(); s++) {
+            L.slice_width[s0 + s] = T.widths[s];
+            L.slice_off[s0 + s] = off;
+            off += (int64_t)T.widths[s] * kLanes;
+        }
+        std::memcpy(&L.slice_major[(size_t)s0 * kLanes], T.lanes.data(), T.lanes.size() * sizeof(uint32_t));
+    }
+    L.n_slots = off;
+    try {
+        if (L.wide) { L.wide_idx.assign(L.n_slots, 0u); L.wide_val.assign(L.n_slots, 0.0); }
+        else L.packed.assign(L.n_slots, 0u);
+    } catch (const std::bad_alloc &) {
+        return fail(VBNMF_ERR_OOM, "out of host memory building the tiled layout (%lld slots)", (long long)L.n_slots);
+    }
+
+    // fill: slot(t, lane) = off + (t/4)*256 + lane*4 + t%4 ; padding slots stay {minor 0, value 0}
+    parallel_for(L.n_tiles, [&](int64_t b, int64_t e, int) {
+        for (int64_t o = b; o < e; o++) {
+            int32_t blk = L.tile_block[o];
+            int32_t m0 = blk * C;
+            for (int64_t s = L.tile_slice0[o]; s < L.tile_slice0[o + 1]; s++) {
+                int64_t so = L.slice_off[s];
+                for (int lane = 0; lane < kLanes; lane++) {
+                    uint32_t M = L.slice_major[(size_t)s * kLanes + lane];
+                    if (M == kIdleLane) continue;
+                    const int64_t *bp = &bpos[(size_t)M * (nblk + 1)];
+                    int64_t q0 = bp[blk], cnt = bp[blk + 1] - q0;
+                    for (int64_t t = 0; t < cnt; t++) {
+                        int64_t slot = so + (t / kUnroll) * (kLanes * kUnroll) + lane * kUnroll + (t % kUnroll);
+                        uint32_t local = (uint32_t)(idx[q0 + t] - m0);
+                        if (L.wide) { L.wide_idx[slot] = local; L.wide_val[slot] = val[q0 + t]; }
+                        else L.packed[slot] = ((uint32_t)val[q0 + t] << 16) | local;
+                    }
+                }
+            }
+        }
+    });
+    return VBNMF_OK;
+}
+
+}  // namespace vbnmf
+
+// ====================================================================== C ABI (host-only part)
+using namespace vbnmf;
+
+extern "C" {
+
+const char *vbnmf_last_error(void) { return vbnmf::last_error_cstr(); }
+const char *vbnmf_version(void) { return "0.1.0"; }
+
+static int new_matrix(vbnmf_matrix **out, const std::function<int(Matrix &)> &fill)
+{
+    if (!out) return fail(VBNMF_ERR_BAD_ARG, "out pointer is NULL");
+    *out = nullptr;
+    vbnmf_matrix *X = nullptr;
+    try {
+        X = new vbnmf_matrix();
+        int rc = fill(X->M);
+        if (rc) { delete X; return rc; }
+        X->lgx = sum_lgamma_x1(X->M, 0, X->M.m);
+    } catch (const std::bad_alloc &) {
+        delete X;
+        return fail(VBNMF_ERR_OOM, "out of host memory ingesting X");
+    } catch (const std::exception &ex) {
+        delete X;
+        return fail(VBNMF_ERR_BAD_ARG, "ingesting X failed: %s", ex.what());
+    }
+    *out = X;
+    return VBNMF_OK;
+}
+
+static int check_dims(int64_t n, int64_t m)
+{
+    if (n <= 0 || m <= 0) return fail(VBNMF_ERR_BAD_ARG, "matrix dimensions must be positive (got %lld x %lld)", (long long)n, (long long)m);
+    if (n > 0x7FFFFFFFLL - 64 || m > 0x7FFFFFFFLL - 64) return fail(VBNMF_ERR_BAD_ARG, "a matrix dimension exceeds 2^31-65");
+    return VBNMF_OK;
+}
+
+int vbnmf_matrix_from_dense(int64_t n, int64_t m, const double *A, vbnmf_matrix **out)
+{
+    if (int rc = check_dims(n, m)) return rc;
+    if (!A) return fail(VBNMF_ERR_BAD_ARG, "X is NULL");
+    return new_matrix(out, [&](Matrix &M) { return matrix_from_dense(n, m, A, M); });
+}
+
+int vbnmf_matrix_from_csc(int64_t n, int64_t m, const int32_t *p, const int32_t *i, const double *x, vbnmf_matrix **out)
+{
+    if (int rc = check_dims(n, m)) return rc;
+    if (!p || ((!i || !x) && p[m] > 0)) return fail(VBNMF_ERR_BAD_ARG, "a CSC slot pointer is NULL");
+    return new_matrix(out, [&](Matrix &M) { return matrix_from_csc(n, m, p, i, x, M); });
+}
+
+int vbnmf_matrix_from_csr(int64_t n, int64_t m, const int32_t *p, const int32_t *j, const double *x, vbnmf_matrix **out)
+{
+    if (int rc = check_dims(n, m)) return rc;
+    if (!p || ((!j || !x) && p[n] > 0)) return fail(VBNMF_ERR_BAD_ARG, "a CSR slot pointer is NULL");
+    return new_matrix(out, [&](Matrix &M) { return matrix_from_csr(n, m, p, j, x, M); });
+}
+
+int vbnmf_matrix_info(const vbnmf_matrix *X, int64_t *n, int64_t *m, int64_t *nnz, double *lgx)
+{
+    if (!X) return fail(VBNMF_ERR_BAD_ARG, "matrix handle is NULL");
+    if (n) *n = X->M.n;
+    if (m) *m = X->M.m;
+    if (nnz) *nnz = X->M.nnz;
+    if (lgx) *lgx = X->lgx;
+    return VBNMF_OK;
+}
+
+int vbnmf_matrix_empty_counts(const vbnmf_matrix *X, int64_t *empty_rows, int64_t *empty_cols)
+{
+    if (!X) return fail(VBNMF_ERR_BAD_ARG, "matrix handle is NULL");
+    const Matrix &M = X->M;
+    // rowSums(mat)==0 / colSums(mat)==0 of reference R/bayesian.R:244-245 (sums, not stored-entry counts)
+    std::vector<double> rs(M.n, 0.0);
+    int64_t ec = 0;
+    for (int64_t j = 0; j < M.m; j++) {
+        double cs = 0.0;
+        for (int64_t e = M.colptr[j]; e < M.colptr[j + 1]; e++) { cs += M.val[e]; rs[M.row[e]] += M.val[e]; }
+        ec += (cs == 0.0);
+    }
+    int64_t er = 0;
+    for (double v : rs) er += (v == 0.0);
+    if (empty_rows) *empty_rows = er;
+    if (empty_cols) *empty_cols = ec;
+    return VBNMF_OK;
+}
+
+void vbnmf_matrix_destroy(vbnmf_matrix *X) { delete X; }
+
+int vbnmf_layout_build(const vbnmf_matrix *X, int64_t col_begin, int64_t col_end, int32_t side, int32_t r,
+                       vbnmf_layout **out, vbnmf_layout_view *view)
+{
+    if (!X || !out || !view) return fail(VBNMF_ERR_BAD_ARG, "NULL argument");
+    if (side != 0 && side != 1) return fail(VBNMF_ERR_BAD_ARG, "side must be 0 or 1");
+    if (r < 1 || r > VBNMF_MAX_RANK) return fail(VBNMF_ERR_BAD_ARG, "rank %d is outside [1, %d]", r, VBNMF_MAX_RANK);
+    *out = nullptr;
+    vbnmf_layout *H = nullptr;
+    try {
+        H = new vbnmf_layout();
+        int R = padded_rank(r);
+        int64_t nmaj = side == 0 ? X->M.n : col_end - col_begin;
+        int64_t nmin = side == 0 ? col_end - col_begin : X->M.n;
+        LayoutParams lp = default_layout_params(nmaj, nmin, R);
+        int rc = build_layout(X->M, col_begin, col_end, side, lp, H->L);
+        if (rc) { delete H; return rc; }
+    } catch (const std::bad_alloc &) {
+        delete H;
+        return fail(VBNMF_ERR_OOM, "out of host memory building the layout");
+    }
+    const Layout &L = H->L;
+    view->side = L.side; view->wide = L.wide ? 1 : 0;
+    view->n_major = L.n_major; view->n_minor = L.n_minor;
+    view->block_width = L.block_width; view->n_blocks = L.n_blocks; view->chunk = L.chunk;
+    view->n_tiles = L.n_tiles; view->n_slices = L.n_slices; view->n_slots = L.n_slots;
+    view->tile_block = L.tile_block.data(); view->tile_slice0 = L.tile_slice0.data();
+    view->slice_major = L.slice_major.data(); view->slice_width = L.slice_width.data();
+    view->slice_off = L.slice_off.data();
+    view->packed = L.wide ? nullptr : L.packed.data();
+    view->wide_idx = L.wide ? L.wide_idx.data() : nullptr;
+    view->wide_val = L.wide ? L.wide_val.data() : nullptr;
+    *out = H;
+    return VBNMF_OK;
+}
+
+void vbnmf_layout_destroy(vbnmf_layout *L) { delete L; }
+
+}  // extern "C"

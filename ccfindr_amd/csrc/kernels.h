@@ -1,0 +1,326 @@
+// kernels.h -- hand-written gfx950 kernels of the VB-NMF step (included once, by engine.hip).
+//
+// Device state layout (all fp64, "index-major": one factor row = R contiguous doubles,
+// R = rank padded to even, pad columns hold 0):
+//   lw, llw, ew, dw : [n][R]       llw = lw * log(lw)
+//   lh, llh, eh, dh : [m][R]       llh = lh * log(lh)
+//   part{A,B}       : [n_blocks][n_major][R]  per-(major, minor-block) partial statistics
+//
+// Mathematics (reference src/vbnmf_update.cpp, all citations to that file):
+//   sweep     :33-36  wth_ij = sum_k lw_ik lh_kj ; q_ij = X_ij / wth_ij ;
+//                     accA_ik = sum_j q_ij lh_kj  (sw = lw .* accA) ; accB_kj = sum_i lw_ik q_ij
+//             :67-77  the data part of the evidence, using on the SAME (new) lw, lh the identity
+//                     sum_ij X_ij (A+B)_ij / wth_ij = sum_ik sw_ik log lw_ik + sum_kj sh_kj log lh_kj
+//                     (A = (lw.*log lw) lh, B = lw (lh.*log lh)), so one pass over X yields the
+//                     statistics of step t+1 and the evidence of step t.
+//   update    :38-65  Gamma posterior shape/rate, means, variances, geometric means;
+//             :82-89  the prior/entropy terms of the evidence.
+//   final     :78,90  -sum(ew*eh) = -sum_k colSum(ew)_k rowSum(eh)_k ; U / (n*m).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "special.h"
+
+namespace vbnmf {
+
+constexpr uint32_t kIdle = 0xFFFFFFFFu;
+
+// ------------------------------------------------------------------------------------
+// Sweep: one workgroup per tile = (chunk of majors) x (block of minors).  The minor
+// block of the gathered factor G sits in LDS; each lane owns one major (its factor row
+// F and R accumulators live in VGPRs) and walks that major's entries in the tile, which
+// are stored lane-interleaved so a wave reads 1 KiB per load instruction.
+// ------------------------------------------------------------------------------------
+struct SweepSide {
+    const uint32_t *packed;        // (count << 16) | local minor          (packed layout)
+    const uint32_t *widx;          // local minor                           (wide layout)
+    const double *wval;            // value                                 (wide layout)
+    const uint32_t *slice_major;   // [n_slices][64]
+    const int32_t *slice_width;    // [n_slices]
+    const int64_t *slice_off;      // [n_slices]
+    const int32_t *tile_block;     // [n_tiles]
+    const int64_t *tile_slice0;    // [n_tiles + 1]
+    const double *F;               // [n_major][R]  factor owned by the lanes
+    const double *llF;             // [n_major][R]  F * log F
+    const double *G;               // [n_minor][R]  factor gathered through LDS
+    double *part;                  // [n_blocks][n_major][R]
+    double *epart;                 // [n_slices] evidence partials
+    int64_t n_major;
+    int32_t n_minor;
+    int32_t block_width;
+    int32_t logterm;               // this side also accumulates sum x*log(wth)
+    int32_t n_tiles;
+};
+
+template <int R>
+struct SweepRegs {
+    double F[R];
+    double acc[R];
+    double lsum;
+};
+
+template <int R>
+__device__ __forceinline__ void sweep_entry(SweepRegs<R> &S, const double2 *__restrict__ ldsG, uint32_t idx,
+                                            double x, bool live, bool logterm)
+{
+    const double2 *g = ldsG + idx * (R / 2);
+    double2 gv[R / 2];
+#pragma unroll
+    for (int kk = 0; kk < R / 2; kk++) gv[kk] = g[kk];
+    double wth = 0.0;
+#pragma unroll
+    for (int kk = 0; kk < R / 2; kk++) {
+        wth = fma(S.F[2 * kk], gv[kk].x, wth);
+        wth = fma(S.F[2 * kk + 1], gv[kk].y, wth);
+    }
+    const double q = live ? x / wth : 0.0;
+#pragma unroll
+    for (int kk = 0; kk < R / 2; kk++) {
+        S.acc[2 * kk] = fma(q, gv[kk].x, S.acc[2 * kk]);
+        S.acc[2 * kk + 1] = fma(q, gv[kk].y, S.acc[2 * kk + 1]);
+    }
+    if (logterm) S.lsum = fma(x, live ? log(wth) : 0.0, S.lsum);
+}
+
+template <int R, bool WIDE, int NT>
+__global__ __launch_bounds__(NT) void k_sweep(const SweepSide A, const SweepSide B)
+{
+    extern __shared__ double2 ldsG[];
+    const bool second = (int)blockIdx.x >= A.n_tiles;
+    const SweepSide &S = second ? B : A;
+    const int tile = (int)blockIdx.x - (second ? A.n_tiles : 0);
+    const int blk = S.tile_block[tile];
+    const int64_t s0 = S.tile_slice0[tile], s1 = S.tile_slice0[tile + 1];
+    const int m0 = blk * S.block_width;
+    const int cw = min(S.block_width, S.n_minor - m0);
+    const bool logterm = S.logterm != 0;
+
+    // stage the minor block of G: cw rows of R doubles, contiguous in HBM
+    {
+        const double2 *G2 = reinterpret_cast<const double2 *>(S.G + (size_t)m0 * R);
+        const int cnt = cw * (R / 2);
+        for (int t = threadIdx.x; t < cnt; t += NT) ldsG[t] = G2[t];
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t s = s0 + wave; s < s1; s += NT / 64) {
+        const uint32_t M = S.slice_major[s * 64 + lane];
+        const int w = S.slice_width[s];
+        const int64_t off = S.slice_off[s];
+        SweepRegs<R> T;
+        if (M != kIdle) {
+            const double2 *F2 = reinterpret_cast<const double2 *>(S.F + (size_t)M * R);
+#pragma unroll
+            for (int kk = 0; kk < R / 2; kk++) { double2 v = F2[kk]; T.F[2 * kk] = v.x; T.F[2 * kk + 1] = v.y; }
+        } else {
+#pragma unroll
+            for (int k = 0; k < R; k++) T.F[k] = 1.0;   // idle lane: only sees padding slots
+        }
+#pragma unroll
+        for (int k = 0; k < R; k++) T.acc[k] = 0.0;
+        T.lsum = 0.0;
+
+        const int ng = w >> 2;
+        if (!WIDE) {
+            const uint4 *E = reinterpret_cast<const uint4 *>(S.packed + off) + lane;
+            uint4 e = ng > 0 ? E[0] : make_uint4(0, 0, 0, 0);
+            for (int g = 0; g < ng; g++) {
+                const uint4 c = e;
+                if (g + 1 < ng) e = E[(size_t)(g + 1) * 64];
+                sweep_entry<R>(T, ldsG, c.x & 0xFFFFu, (double)(c.x >> 16), (c.x >> 16) != 0, logterm);
+                sweep_entry<R>(T, ldsG, c.y & 0xFFFFu, (double)(c.y >> 16), (c.y >> 16) != 0, logterm);
+                sweep_entry<R>(T, ldsG, c.z & 0xFFFFu, (double)(c.z >> 16), (c.z >> 16) != 0, logterm);
+                sweep_entry<R>(T, ldsG, c.w & 0xFFFFu, (double)(c.w >> 16), (c.w >> 16) != 0, logterm);
+            }
+        } else {
+            const uint4 *E = reinterpret_cast<const uint4 *>(S.widx + off) + lane;
+            const double2 *V = reinterpret_cast<const double2 *>(S.wval + off) + lane * 2;
+            for (int g = 0; g < ng; g++) {
+                const uint4 c = E[(size_t)g * 64];
+                const double2 v0 = V[(size_t)g * 128], v1 = V[(size_t)g * 128 + 1];
+                sweep_entry<R>(T, ldsG, c.x, v0.x, v0.x != 0.0, logterm);
+                sweep_entry<R>(T, ldsG, c.y, v0.y, v0.y != 0.0, logterm);
+                sweep_entry<R>(T, ldsG, c.z, v1.x, v1.x != 0.0, logterm);
+                sweep_entry<R>(T, ldsG, c.w, v1.y, v1.y != 0.0, logterm);
+            }
+        }
+
+        // partial statistics of this (major, block) and the lane's evidence contribution
+        double ev = 0.0;
+        if (M != kIdle) {
+            double2 *P = reinterpret_cast<double2 *>(S.part + ((size_t)blk * S.n_major + M) * R);
+            const double2 *L2 = reinterpret_cast<const double2 *>(S.llF + (size_t)M * R);
+#pragma unroll
+            for (int kk = 0; kk < R / 2; kk++) {
+                P[kk] = make_double2(T.acc[2 * kk], T.acc[2 * kk + 1]);
+                const double2 l = L2[kk];
+                ev = fma(T.acc[2 * kk], l.x, ev);
+                ev = fma(T.acc[2 * kk + 1], l.y, ev);
+            }
+            ev -= T.lsum;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) ev += __shfl_down(ev, d, 64);
+        if (lane == 0) S.epart[s] = ev;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Posterior update of one factor (both sides share it).  One thread per (major, k).
+//   s   = sum_b acc[b][major][k]            partial statistics of the previous sweep
+//   al  = a + l_old * s                     :38-39 / :48-49
+//   be  = a/b + other[k]                    :40-43 (rowSums of the incoming eh) / :50-53 (colSums of the NEW ew)
+//   e   = al/be ; d = al/be/be              :44,46 / :54,56
+//   l   = max(exp(psi(al))/be, fudge)       :58-65
+//   term= -(a/b) e + lga + al (1 - log be) + lgamma(al)     :82-89
+// Block partials (fixed-order tree over the block's rows): bp[block][0..R) = sum e per k,
+// bp[block][R] = sum term, bp[block][R+1] = sum log l.
+// ------------------------------------------------------------------------------------
+template <int R>
+__global__ __launch_bounds__(256) void k_update(const double *__restrict__ acc, int nacc, int64_t nmaj, int r,
+                                                const double *__restrict__ other, double a, double b, double lga,
+                                                double fudge, double *__restrict__ l, double *__restrict__ ll,
+                                                double *__restrict__ e, double *__restrict__ d, double *__restrict__ bp)
+{
+    constexpr int RB = 256 / R;                  // rows per block
+    __shared__ double s_e[256], s_t[256], s_l[256];
+    const int t = threadIdx.x;
+    const int row = t / R, k = t - row * R;
+    const int64_t M = (int64_t)blockIdx.x * RB + row;
+    double ve = 0.0, vt = 0.0, vl = 0.0;
+    if (row < RB && M < nmaj) {
+        const size_t o = (size_t)M * R + k;
+        if (k < r) {
+            double s = 0.0;
+            for (int q = 0; q < nacc; q++) s += acc[(size_t)q * nmaj * R + o];
+            const double al = a + l[o] * s;
+            const double be = a / b + other[k];
+            ve = al / be;
+            const double dv = al / be / be;
+            const double tmp = exp(dev_digamma(al)) / be;
+            const double ln = (tmp > fudge ? tmp : fudge);
+            const double lg = log(ln);
+            vt = -(a / b) * ve + lga + al * (1.0 - log(be)) + dev_lgamma(al);
+            vl = lg;
+            l[o] = ln; ll[o] = ln * lg; e[o] = ve; d[o] = dv;
+        } else {
+            l[o] = 0.0; ll[o] = 0.0; e[o] = 0.0; d[o] = 0.0;
+        }
+    }
+    s_e[t] = ve; s_t[t] = vt; s_l[t] = vl;
+    __syncthreads();
+    constexpr int P2 = (RB <= 1) ? 1 : (RB <= 2) ? 2 : (RB <= 4) ? 4 : (RB <= 8) ? 8 : (RB <= 16) ? 16
+                     : (RB <= 32) ? 32 : (RB <= 64) ? 64 : 128;
+    for (int h = P2 / 2; h >= 1; h >>= 1) {
+        if (row < h && row + h < RB) {
+            s_e[t] += s_e[t + h * R]; s_t[t] += s_t[t + h * R]; s_l[t] += s_l[t + h * R];
+        }
+        __syncthreads();
+    }
+    double *o = bp + (size_t)blockIdx.x * (R + 2);
+    if (t < R) o[t] = s_e[t];
+    if (t == 0) {
+        double st = 0.0, sl = 0.0;
+        for (int q = 0; q < R; q++) { st += s_t[q]; sl += s_l[q]; }
+        o[R] = st; o[R + 1] = sl;
+    }
+}
+
+// State load (set_state): ll = l*log(l) and the block partials of e's column sums, same
+// bp layout as k_update (term and log-sum columns are written as 0).
+template <int R>
+__global__ __launch_bounds__(256) void k_prime(int64_t nmaj, int r, const double *__restrict__ l,
+                                               double *__restrict__ ll, const double *__restrict__ e,
+                                               double *__restrict__ bp)
+{
+    constexpr int RB = 256 / R;
+    __shared__ double s_e[256];
+    const int t = threadIdx.x;
+    const int row = t / R, k = t - row * R;
+    const int64_t M = (int64_t)blockIdx.x * RB + row;
+    double ve = 0.0;
+    if (row < RB && M < nmaj) {
+        const size_t o = (size_t)M * R + k;
+        if (k < r) { const double v = l[o]; ll[o] = v * log(v); if (e) ve = e[o]; }
+        else ll[o] = 0.0;
+    }
+    s_e[t] = ve;
+    __syncthreads();
+    constexpr int P2 = (RB <= 1) ? 1 : (RB <= 2) ? 2 : (RB <= 4) ? 4 : (RB <= 8) ? 8 : (RB <= 16) ? 16
+                     : (RB <= 32) ? 32 : (RB <= 64) ? 64 : 128;
+    for (int h = P2 / 2; h >= 1; h >>= 1) {
+        if (row < h && row + h < RB) s_e[t] += s_e[t + h * R];
+        __syncthreads();
+    }
+    double *o = bp + (size_t)blockIdx.x * (R + 2);
+    if (t < R) o[t] = s_e[t];
+    if (t == 0) { o[R] = 0.0; o[R + 1] = 0.0; }
+}
+
+// ------------------------------------------------------------------------------------
+// Fixed-order reductions.  Block c < ncols sums column c of a row-major [count][stride]
+// table into dst[c]; block ncols (if vsrc) sums the vector vsrc[0..vcount) into *vdst.
+// Thread t adds elements t, t+256, ... in order, then a binary tree over the 256 threads.
+// ------------------------------------------------------------------------------------
+struct ReduceArgs {
+    const double *src; int64_t count; int64_t stride; int ncols; double *dst;
+    const double *vsrc; int64_t vcount; double *vdst;
+    double *cdst; double cval;        // optional constant to (re)write beside the sums
+};
+
+__global__ __launch_bounds__(256) void k_reduce(const ReduceArgs a)
+{
+    __shared__ double sm[256];
+    const int t = threadIdx.x;
+    const int c = blockIdx.x;
+    double s = 0.0;
+    if (c < a.ncols) {
+        for (int64_t q = t; q < a.count; q += 256) s += a.src[q * a.stride + c];
+    } else {
+        for (int64_t q = t; q < a.vcount; q += 256) s += a.vsrc[q];
+    }
+    sm[t] = s;
+    __syncthreads();
+    for (int h = 128; h >= 1; h >>= 1) {
+        if (t < h) sm[t] += sm[t + h];
+        __syncthreads();
+    }
+    if (t == 0) {
+        if (c < a.ncols) a.dst[c] = sm[0];
+        else { *a.vdst = sm[0]; if (a.cdst) *a.cdst = a.cval; }
+    }
+}
+
+// swsum[e] = sum_b part[b][e]  (e over n_major*R), blocks in index order.
+__global__ __launch_bounds__(256) void k_pack(const double *__restrict__ part, int nblk, int64_t count,
+                                              double *__restrict__ out)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= count) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; b++) s += part[(size_t)b * count + e];
+    out[e] = s;
+}
+
+// Evidence and the four hyper statistics from the reduced scalars.
+//   outW : [R+2]  colSum(ew)_k, sum W-terms, sum log lw          (replicated)
+//   tail : [R+4]  rowSum(eh)_k, sum H-terms, sum log lh, data term, sum lgamma(x+1)   (summed over partitions)
+//   out  : lkh, mean log lw, mean log lh, mean ew, mean eh
+template <int R>
+__global__ void k_final(const double *__restrict__ outW, const double *__restrict__ tail, int r, double n,
+                        double m_global, double *__restrict__ out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double cross = 0.0, sew = 0.0, seh = 0.0;
+    for (int k = 0; k < r; k++) { cross += outW[k] * tail[k]; sew += outW[k]; seh += tail[k]; }
+    const double U = -cross - tail[R + 2] - tail[R + 3] + outW[R] + tail[R];
+    out[0] = U / (n * m_global);
+    out[1] = outW[R + 1] / (n * r);
+    out[2] = tail[R + 1] / (m_global * r);
+    out[3] = sew / (n * r);
+    out[4] = seh / (m_global * r);
+}
+
+}  // namespace vbnmf

@@ -1,0 +1,203 @@
+"""Host-side objects over the C ABI: the ingested count matrix and the device-resident engine.
+
+``CountMatrix`` is what ``counts(object)`` is to the reference driver (reference
+R/bayesian.R:239): the genes x cells count matrix, dense or ``dgCMatrix``-like sparse.
+``VBEngine`` holds what ``vb_iterate`` carries from one ``vbnmf_update`` call to the next
+(``wh``; reference R/bayesian.R:334-339) in HBM and runs the step there.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _native as N
+
+EPS = float(np.finfo(np.float64).eps)    # .Machine$double.eps, the default fudge (reference R/bayesian.R:238)
+
+
+class CountMatrix:
+    """X ingested once into the library's canonical sparse copy (zeros dropped)."""
+
+    def __init__(self, X):
+        L = N.load()
+        self._h = ctypes.c_void_p()
+        self._lib = L
+        if hasattr(X, "tocsc") and hasattr(X, "indptr"):          # scipy.sparse
+            fmt = getattr(X, "format", None)
+            if fmt == "csr":
+                n, m = X.shape
+                p = np.ascontiguousarray(X.indptr, dtype=np.int32)
+                j = np.ascontiguousarray(X.indices, dtype=np.int32)
+                x = np.ascontiguousarray(X.data, dtype=np.float64)
+                N.check(L.vbnmf_matrix_from_csr(n, m, p.ctypes.data_as(N.c_int32_p), j.ctypes.data_as(N.c_int32_p),
+                                                N.dptr(x), ctypes.byref(self._h)))
+            else:
+                X = X.tocsc()
+                n, m = X.shape
+                p = np.ascontiguousarray(X.indptr, dtype=np.int32)
+                i = np.ascontiguousarray(X.indices, dtype=np.int32)
+                x = np.ascontiguousarray(X.data, dtype=np.float64)
+                N.check(L.vbnmf_matrix_from_csc(n, m, p.ctypes.data_as(N.c_int32_p), i.ctypes.data_as(N.c_int32_p),
+                                                N.dptr(x), ctypes.byref(self._h)))
+        else:
+            A = N.fcol(X)
+            if A.ndim != 2:
+                raise ValueError("X must be a 2-d matrix (genes x cells)")
+            n, m = A.shape
+            N.check(L.vbnmf_matrix_from_dense(n, m, N.dptr(A), ctypes.byref(self._h)))
+        n_, m_, nnz_ = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        lgx = ctypes.c_double()
+        N.check(L.vbnmf_matrix_info(self._h, ctypes.byref(n_), ctypes.byref(m_), ctypes.byref(nnz_), ctypes.byref(lgx)))
+        self.shape = (n_.value, m_.value)
+        self.nnz = nnz_.value
+        self.sum_lgamma_x1 = lgx.value
+
+    @classmethod
+    def from_csc(cls, n, m, p, i, x):
+        """dgCMatrix slots: @p, @i, @x (reference R/utils.R:34 reads 10x data into one)."""
+        self = cls.__new__(cls)
+        L = N.load()
+        self._lib = L
+        self._h = ctypes.c_void_p()
+        p = np.ascontiguousarray(p, dtype=np.int32)
+        i = np.ascontiguousarray(i, dtype=np.int32)
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        N.check(L.vbnmf_matrix_from_csc(n, m, p.ctypes.data_as(N.c_int32_p), i.ctypes.data_as(N.c_int32_p),
+                                        N.dptr(x), ctypes.byref(self._h)))
+        nnz_ = ctypes.c_int64()
+        lgx = ctypes.c_double()
+        N.check(L.vbnmf_matrix_info(self._h, None, None, ctypes.byref(nnz_), ctypes.byref(lgx)))
+        self.shape = (int(n), int(m))
+        self.nnz = nnz_.value
+        self.sum_lgamma_x1 = lgx.value
+        return self
+
+    def empty_counts(self):
+        """(# all-zero rows, # all-zero columns): the guards of reference R/bayesian.R:244-247."""
+        er, ec = ctypes.c_int64(), ctypes.c_int64()
+        N.check(self._lib.vbnmf_matrix_empty_counts(self._h, ctypes.byref(er), ctypes.byref(ec)))
+        return er.value, ec.value
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.vbnmf_matrix_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _CudaBuffer:
+    """Exposes a raw device pointer through __cuda_array_interface__ (for torch.as_tensor)."""
+
+    def __init__(self, ptr: int, count: int):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+
+class VBEngine:
+    """Device-resident state of one factorisation (one rank, one column block of X)."""
+
+    def __init__(self, X: CountMatrix, rank: int, device: int = 0, cols=None, m_global=None):
+        L = N.load()
+        self._lib = L
+        self._h = ctypes.c_void_p()
+        self.X = X
+        if cols is None:
+            N.check(L.vbnmf_engine_create(X._h, int(rank), int(device), ctypes.byref(self._h)))
+        else:
+            cb, ce = cols
+            mg = X.shape[1] if m_global is None else m_global
+            N.check(L.vbnmf_engine_create_part(X._h, int(cb), int(ce), int(mg), int(rank), int(device), ctypes.byref(self._h)))
+        n, m, r = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int32()
+        N.check(L.vbnmf_engine_dims(self._h, ctypes.byref(n), ctypes.byref(m), ctypes.byref(r)))
+        self.n, self.m, self.rank = n.value, m.value, r.value
+        self.device = int(device)
+
+    # -- state ---------------------------------------------------------------------------
+    def set_state(self, lw, lh, eh, finish=True):
+        lw, lh, eh = N.fcol(lw), N.fcol(lh), N.fcol(eh)
+        if lw.shape != (self.n, self.rank) or lh.shape != (self.rank, self.m) or eh.shape != (self.rank, self.m):
+            raise ValueError(f"state shapes must be lw {(self.n, self.rank)}, lh/eh {(self.rank, self.m)}")
+        N.check(self._lib.vbnmf_engine_set_state(self._h, N.dptr(lw), N.dptr(lh), N.dptr(eh)))
+
+    def state_finish(self):
+        N.check(self._lib.vbnmf_engine_state_finish(self._h))
+
+    def get_state(self, names=("lw", "lh", "ew", "eh", "dw", "dh")):
+        out = {}
+        for k in ("lw", "ew", "dw"):
+            out[k] = np.empty((self.n, self.rank), order="F") if k in names else None
+        for k in ("lh", "eh", "dh"):
+            out[k] = np.empty((self.rank, self.m), order="F") if k in names else None
+        N.check(self._lib.vbnmf_engine_get_state(self._h, N.dptr(out["lw"]), N.dptr(out["lh"]), N.dptr(out["ew"]),
+                                                 N.dptr(out["eh"]), N.dptr(out["dw"]), N.dptr(out["dh"])))
+        return {k: v for k, v in out.items() if v is not None}
+
+    # -- stepping ------------------------------------------------------------------------
+    def step(self, hyper, fudge=EPS):
+        """One vbnmf_update on the resident state -> (lkh, stats) with
+        stats = (mean log lw, mean log lh, mean ew, mean eh)."""
+        lkh = ctypes.c_double()
+        st = (ctypes.c_double * 4)()
+        N.check(self._lib.vbnmf_engine_step(self._h, hyper["aw"], hyper["bw"], hyper["ah"], hyper["bh"], float(fudge),
+                                            ctypes.byref(lkh), st))
+        return lkh.value, tuple(st)
+
+    def step_local(self, hyper, fudge=EPS):
+        N.check(self._lib.vbnmf_engine_step_local(self._h, hyper["aw"], hyper["bw"], hyper["ah"], hyper["bh"], float(fudge)))
+
+    def step_finish(self):
+        lkh = ctypes.c_double()
+        st = (ctypes.c_double * 4)()
+        N.check(self._lib.vbnmf_engine_step_finish(self._h, ctypes.byref(lkh), st))
+        return lkh.value, tuple(st)
+
+    def reduce_buffer(self):
+        """(device pointer, count of doubles) of the buffer a partitioned run all-reduces."""
+        p, c = ctypes.c_void_p(), ctypes.c_int64()
+        N.check(self._lib.vbnmf_engine_reduce_buffer(self._h, ctypes.byref(p), ctypes.byref(c)))
+        return p.value, c.value
+
+    def reduce_tensor(self):
+        """The reduce buffer as a torch CUDA tensor aliasing the engine's memory."""
+        import torch
+        p, c = self.reduce_buffer()
+        return torch.as_tensor(_CudaBuffer(p, c), device=f"cuda:{self.device}")
+
+    def stream(self):
+        s = ctypes.c_void_p()
+        N.check(self._lib.vbnmf_engine_get_stream(self._h, ctypes.byref(s)))
+        return s.value
+
+    def set_stream(self, stream_ptr: int):
+        N.check(self._lib.vbnmf_engine_set_stream(self._h, ctypes.c_void_p(stream_ptr)))
+
+    # -- instrumentation -------------------------------------------------------------------
+    def timing_enable(self, on=True):
+        N.check(self._lib.vbnmf_engine_timing_enable(self._h, 1 if on else 0))
+
+    def timing_get(self):
+        ms, cnt = ctypes.c_double(), ctypes.c_int64()
+        N.check(self._lib.vbnmf_engine_timing_get(self._h, ctypes.byref(ms), ctypes.byref(cnt)))
+        return ms.value, cnt.value
+
+    def layout_info(self):
+        v = [ctypes.c_int64() for _ in range(6)]
+        N.check(self._lib.vbnmf_engine_layout_info(self._h, *[ctypes.byref(x) for x in v]))
+        keys = ("nnz", "slots_gene_side", "slots_cell_side", "stream_bytes_per_step", "tiles_gene_side", "tiles_cell_side")
+        return dict(zip(keys, (x.value for x in v)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.vbnmf_engine_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,205 @@
+/*
+ * vbnmf.h -- C ABI of the MI355X-native VB-NMF update engine (libvbnmf_hip.so).
+ *
+ * Drop-in boundary for ONE path of ccfindR: the variational-Bayes NMF update step
+ *     Rcpp::List vbnmf_update(const Eigen::MatrixXd& X, const Rcpp::List& wh,
+ *                             const Rcpp::List& hyper, const Rcpp::NumericVector& fudge)
+ * (reference src/vbnmf_update.cpp:16-17), reached from R through
+ *     .Call(`_ccfindR_vbnmf_update`, X, wh, hyper, fudge)
+ * (reference R/RcppExports.R:4-6, src/RcppExports.cpp:11-22) and called only by
+ * vb_iterate (reference R/bayesian.R:339).  INTEGRATION.md shows the Rcpp shim that
+ * binds these entry points under the reference's own .Call symbol.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every function returns a vbnmf_status (0 = ok) and
+ *     never throws or aborts; vbnmf_last_error() gives the message of the calling
+ *     thread's last failure (the shim turns it into Rcpp::stop, as END_RCPP does for
+ *     exceptions at src/RcppExports.cpp:21).
+ *   - matrices are column-major fp64 exactly as R / Eigen hold them:
+ *       lw, ew, dw : n x r        lh, eh, dh : r x m        X : n x m
+ *   - dimensions are 64-bit (the reference's `U/=n*m` in int, src/vbnmf_update.cpp:90,
+ *     overflows past 2^31-1 elements; here the product is formed in double as the R twin
+ *     does, R/bayesian.R:97).
+ *   - NaN/Inf are not errors: they propagate into lkh, so the caller's is.na() break
+ *     (R/bayesian.R:345) keeps working.
+ *   - a HIP device is REQUIRED.  There is no CPU fallback: without a usable gfx950
+ *     device every compute entry point fails with VBNMF_ERR_NO_DEVICE.
+ *   - one engine = one device = one host thread at a time; distinct engines may be
+ *     driven from distinct threads / processes (one process per GPU).
+ */
+#ifndef VBNMF_H
+#define VBNMF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    VBNMF_OK = 0,
+    VBNMF_ERR_BAD_ARG = 1,     /* null pointer, non-positive dim, rank out of range, bad index */
+    VBNMF_ERR_NO_DEVICE = 2,   /* no HIP device / device is not usable                          */
+    VBNMF_ERR_HIP = 3,         /* a HIP runtime call failed (message has the HIP error string)  */
+    VBNMF_ERR_OOM = 4,         /* host or device allocation failed                              */
+    VBNMF_ERR_STATE = 5        /* call sequence error (e.g. step before set_state)              */
+} vbnmf_status;
+
+#define VBNMF_MAX_RANK 32
+
+/* Message of the calling thread's most recent failure ("" if none). Never NULL. */
+const char *vbnmf_last_error(void);
+/* "major.minor.patch" of this library. */
+const char *vbnmf_version(void);
+/* Number of visible HIP devices (0 if none / no driver); never fails. */
+int32_t vbnmf_device_count(void);
+
+/* ---------------------------------------------------------------------------------
+ * Count matrix X.  Host-side canonical copy (compressed sparse columns, zeros dropped)
+ * plus the iteration-invariant sum_ij lgamma(X_ij + 1) of src/vbnmf_update.cpp:80-81.
+ * Replaces the per-iteration `as.matrix(bundle$mat)` + Rcpp::as<Eigen::MatrixXd> copy
+ * (R/bayesian.R:339, src/RcppExports.cpp:15): X is ingested ONCE.
+ * --------------------------------------------------------------------------------- */
+typedef struct vbnmf_matrix vbnmf_matrix;
+
+/* Dense n x m column-major doubles (what as.matrix() hands the reference). */
+int vbnmf_matrix_from_dense(int64_t n, int64_t m, const double *X, vbnmf_matrix **out);
+/* dgCMatrix slots (Matrix package; what counts(object) is after read_10x, R/utils.R:34):
+ * p = m+1 column pointers, i = 0-based row indices (any order within a column,
+ * duplicates are summed), x = values. */
+int vbnmf_matrix_from_csc(int64_t n, int64_t m, const int32_t *p, const int32_t *i,
+                          const double *x, vbnmf_matrix **out);
+/* Compressed sparse rows: p = n+1 row pointers, j = 0-based column indices. */
+int vbnmf_matrix_from_csr(int64_t n, int64_t m, const int32_t *p, const int32_t *j,
+                          const double *x, vbnmf_matrix **out);
+/* n, m, stored entries, sum lgamma(x+1); any out pointer may be NULL. */
+int vbnmf_matrix_info(const vbnmf_matrix *X, int64_t *n, int64_t *m, int64_t *nnz,
+                      double *sum_lgamma_x1);
+/* The reference's input guards (R/bayesian.R:244-247): counts of all-zero rows / columns. */
+int vbnmf_matrix_empty_counts(const vbnmf_matrix *X, int64_t *empty_rows, int64_t *empty_cols);
+void vbnmf_matrix_destroy(vbnmf_matrix *X);
+
+/* ---------------------------------------------------------------------------------
+ * Engine: device-resident state of one factorisation of (a column block of) X at one
+ * rank.  Holds what vb_iterate carries between calls, {lw, lh, ew, eh} (R/bayesian.R:
+ * 334-339), in HBM, plus X in the tiled device layout.
+ * --------------------------------------------------------------------------------- */
+typedef struct vbnmf_engine vbnmf_engine;
+
+/* Whole matrix on HIP device `device`, rank 1 <= r <= VBNMF_MAX_RANK. */
+int vbnmf_engine_create(const vbnmf_matrix *X, int32_t r, int32_t device, vbnmf_engine **out);
+/* Cell-partitioned engine: owns columns [col_begin, col_end) of X; m_global = total
+ * number of cells across all partitions (used for the n*m normalisation of lkh).
+ * The gene-side state (lw, ew, dw) is replicated in every partition; the caller sums
+ * the reduce buffer (below) across partitions between step_local and step_finish. */
+int vbnmf_engine_create_part(const vbnmf_matrix *X, int64_t col_begin, int64_t col_end,
+                             int64_t m_global, int32_t r, int32_t device, vbnmf_engine **out);
+void vbnmf_engine_destroy(vbnmf_engine *e);
+
+/* n, local m (cells owned), r. */
+int vbnmf_engine_dims(const vbnmf_engine *e, int64_t *n, int64_t *m_local, int32_t *r);
+
+/* Load wh$lw (n x r), wh$lh (r x m_local), wh$eh (r x m_local): the three members of
+ * `wh` that influence the result (src/vbnmf_update.cpp:22-25; ew is overwritten at :44).
+ * Also (re)computes the sufficient statistics of the new state. */
+int vbnmf_engine_set_state(vbnmf_engine *e, const double *lw, const double *lh, const double *eh);
+
+/* One vbnmf_update step (src/vbnmf_update.cpp:33-90) on the resident state with
+ * hyper = {aw, bw, ah, bh} and fudge.  Outputs:
+ *   lkh      wh$lkh, the log evidence per element (:90)
+ *   stats[4] mean(log lw), mean(log lh), mean(ew), mean(eh) of the NEW state: the four
+ *            reductions hyper_update needs (R/bayesian.R:8-11), so the caller never
+ *            downloads the factors between steps.  May be NULL.
+ * Synchronous from the caller's view (the lkh read-back is the sync point). */
+int vbnmf_engine_step(vbnmf_engine *e, double aw, double bw, double ah, double bh, double fudge,
+                      double *lkh, double *stats);
+
+/* Split form of step for cell-partitioned engines.  step_local enqueues the local work
+ * and leaves this partition's contribution in the reduce buffer (device memory, `count`
+ * doubles); the caller all-reduces (sum) that buffer across partitions on the engine's
+ * stream (RCCL), then step_finish produces lkh/stats (identical on every partition).
+ * For an unpartitioned engine step == step_local; step_finish with no all-reduce. */
+int vbnmf_engine_step_local(vbnmf_engine *e, double aw, double bw, double ah, double bh,
+                            double fudge);
+int vbnmf_engine_reduce_buffer(vbnmf_engine *e, void **device_ptr, int64_t *count);
+int vbnmf_engine_step_finish(vbnmf_engine *e, double *lkh, double *stats);
+/* After set_state on a partitioned engine the initial statistics need the same exchange:
+ * set_state leaves them in the reduce buffer; all-reduce it, then call this. */
+int vbnmf_engine_state_finish(vbnmf_engine *e);
+
+/* Download the current wh members (any pointer may be NULL):
+ * lw, ew, dw : n x r ; lh, eh, dh : r x m_local.  dw, dh are variances, as the reference
+ * returns them (src/vbnmf_update.cpp:46,56); the R driver takes sqrt later (R/bayesian.R:382-383). */
+int vbnmf_engine_get_state(vbnmf_engine *e, double *lw, double *lh, double *ew, double *eh,
+                           double *dw, double *dh);
+
+/* The HIP stream (hipStream_t) the engine launches on, for callers that order other
+ * device work (an RCCL all-reduce) against it; and the option to adopt a caller's stream. */
+int vbnmf_engine_get_stream(vbnmf_engine *e, void **stream);
+int vbnmf_engine_set_stream(vbnmf_engine *e, void *stream);
+
+/* Profiling aid for bench.py: when enabled, every step brackets the sweep kernel with HIP
+ * events on the engine's stream; get returns the accumulated kernel time and launch
+ * count since the last reset and resets them. */
+int vbnmf_engine_timing_enable(vbnmf_engine *e, int32_t on);
+int vbnmf_engine_timing_get(vbnmf_engine *e, double *sweep_ms, int64_t *sweep_launches);
+
+/* Layout facts for roofline accounting / tests (any pointer may be NULL):
+ * padded entry slots and bytes the two sweeps stream per step, tile counts. */
+int vbnmf_engine_layout_info(const vbnmf_engine *e, int64_t *nnz, int64_t *slots_gene_side,
+                             int64_t *slots_cell_side, int64_t *stream_bytes_per_step,
+                             int64_t *tiles_gene_side, int64_t *tiles_cell_side);
+
+/* ---------------------------------------------------------------------------------
+ * Stateless form: the reference's call, one X in, one updated `wh` out
+ * (src/vbnmf_update.cpp:16-101).  Builds a throw-away engine on device 0; use the
+ * engine API in a loop.  Outputs as the returned list's lw, lh, ew (= w), eh (= h),
+ * dw, dh, lkh (:92-100).
+ * --------------------------------------------------------------------------------- */
+int vbnmf_update_dense(int64_t n, int64_t m, int32_t r, const double *X,
+                       const double *lw_in, const double *lh_in, const double *eh_in,
+                       double aw, double bw, double ah, double bh, double fudge,
+                       double *lw, double *lh, double *ew, double *eh,
+                       double *dw, double *dh, double *lkh);
+/* Same with X as dgCMatrix slots (no densification on the R side). */
+int vbnmf_update_csc(int64_t n, int64_t m, int32_t r, const int32_t *p, const int32_t *i,
+                     const double *x,
+                     const double *lw_in, const double *lh_in, const double *eh_in,
+                     double aw, double bw, double ah, double bh, double fudge,
+                     double *lw, double *lh, double *ew, double *eh,
+                     double *dw, double *dh, double *lkh);
+
+/* ---------------------------------------------------------------------------------
+ * Host-only inspection of the tiled device layout (no GPU needed): builds the layout
+ * for one side at padded rank r and hands out its arrays so tests can check, bit for
+ * bit, that the tiles hold exactly X.  side 0 = gene side (lanes own genes, minor =
+ * cells), 1 = cell side.  The returned pointers belong to the layout object.
+ * --------------------------------------------------------------------------------- */
+typedef struct vbnmf_layout vbnmf_layout;
+typedef struct {
+    int32_t side, wide;            /* wide: 0 = packed u16 index | u16 count, 1 = u32 index + f64 value */
+    int64_t n_major, n_minor;      /* lanes own majors; minors are gathered from LDS */
+    int32_t block_width;           /* minors per LDS block */
+    int32_t n_blocks;              /* ceil(n_minor / block_width) */
+    int32_t chunk;                 /* majors per tile (multiple of 64) */
+    int64_t n_tiles, n_slices;     /* tile = (major chunk, minor block); slice = 64 lanes */
+    int64_t n_slots;               /* padded entry slots (all slices) */
+    const int32_t *tile_block;     /* [n_tiles] minor block of the tile */
+    const int64_t *tile_slice0;    /* [n_tiles+1] first slice of each tile */
+    const uint32_t *slice_major;   /* [n_slices*64] major id per lane, 0xFFFFFFFF = idle lane */
+    const int32_t *slice_width;    /* [n_slices] entries per lane (multiple of 4) */
+    const int64_t *slice_off;      /* [n_slices] first slot of the slice; slot(t, lane) =
+                                      off + (t/4)*256 + lane*4 + t%4 */
+    const uint32_t *packed;        /* [n_slots] (count << 16) | local minor    (wide == 0) */
+    const uint32_t *wide_idx;      /* [n_slots] local minor                    (wide == 1) */
+    const double *wide_val;        /* [n_slots]                                (wide == 1) */
+} vbnmf_layout_view;
+
+int vbnmf_layout_build(const vbnmf_matrix *X, int64_t col_begin, int64_t col_end, int32_t side,
+                       int32_t r, vbnmf_layout **out, vbnmf_layout_view *view);
+void vbnmf_layout_destroy(vbnmf_layout *L);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VBNMF_H */
