@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py -- VB-NMF update iterations/sec on the BASELINE.json headline workload.
+
+Workload (config C3 of BASELINE.json / SURVEY.md section 8d): a 20 000-gene x 50 000-cell synthetic
+sparse count matrix (Dirichlet-multinomial cluster mixture, ~5 % non-zero), rank 10,
+hyper-parameters fixed at aw=bw=ah=bh=1, fudge = double eps.  A "step" is one full
+vbnmf_update iteration (reference src/vbnmf_update.cpp:33-90, evidence included) on the
+device-resident state, with lkh and the four hyper statistics read back to the host, as the
+reference's caller needs them every iteration (reference R/bayesian.R:345-347).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--mode restarts|cells] [--small]
+
+N > 1 (launched by torch.distributed.run, one process per GPU):
+  --mode restarts (default)  every GPU runs an independent restart of the same factorisation
+                             (the reference's own parallelism: mpi.applyLB over runs, reference
+                             R/bayesian.R:263); no data-path collective; weak scaling;
+                             value = N * K / time.
+  --mode cells               one factorisation, cells partitioned over the GPUs, one RCCL
+                             all-reduce of [sw | rowSums(eh) | scalars] per step; strong scaling.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+HYPER = {"aw": 1.0, "bw": 1.0, "ah": 1.0, "bh": 1.0}
+
+
+def make_workload(small: bool):
+    from ccfindr_amd import synth
+    if small:
+        n, m, r, k = 2000, 5000, 10, 5
+        depth = None
+        X = synth.simulate_data(n, [m // k] * k, alpha0=0.1, seed=3, nfactor=1)
+        name = "C3-small 2k x 5k sparse, rank 10"
+    else:
+        n, m, r, k = 20000, 50000, 10, 10
+        rng = np.random.default_rng(3)
+        depth = np.round(rng.lognormal(np.log(1500.0), 0.3, size=m)).astype(np.int64)
+        X = synth.simulate_data(n, [m // k] * k, alpha0=0.065, seed=3, depth=depth)
+        name = "C3 20k x 50k CSR-sparse (~5% nnz), rank 10"
+    X = synth.fill_empty(X, seed=3)
+    return name, X, r
+
+
+def algorithmic_bytes(n, m, r, nnz):
+    """canonical CSR fp64 value + int32 index, fp64 factors."""
+    x_pass = 12 * nnz + 4 * (n + 1)
+    bytes_iter = x_pass + 48 * (n * r + r * m)
+    sweep = x_pass + 16 * (n * r + r * m)        # read lw, lh once, write the sw, sh statistics once
+    return bytes_iter, sweep
+
+
+def cpu_baseline(X, r, wh0, nsteps):
+    """The oracle's stored-entries restatement (OpenMP, all host cores) on the same workload."""
+    from oracle import vbnmf_oracle as O
+    n, m = X.shape
+    cores = int(O.lib().oracle_max_threads())
+    p, i, x = X.indptr, X.indices, X.data
+    wh = wh0
+    lk = []
+    t0 = time.perf_counter()
+    for _ in range(nsteps):
+        wh = O.update_csc(n, m, p, i, x, wh, HYPER, nthreads=cores)
+        lk.append(wh["lkh"])
+    dt = time.perf_counter() - t0
+    return {"value": nsteps / dt, "unit": "iterations/s", "cores": cores, "kind": "port",
+            "sample": f"{nsteps} full steps of the same workload (oracle update_csc, OpenMP x{cores})"}, lk
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--mode", choices=("restarts", "cells"), default="restarts")
+    ap.add_argument("--small", action="store_true", help="2k x 5k smoke-sized workload (not the headline)")
+    ap.add_argument("--cpu-steps", type=int, default=4)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+
+    import torch
+    import torch.distributed as dist
+    import ccfindr_amd as C
+    from ccfindr_amd import synth
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    name, X, r = make_workload(args.small)
+    n, m = X.shape
+    nnz = int(X.nnz)
+    M = C.CountMatrix(X)
+
+    if args.mode == "cells" and world > 1:
+        from ccfindr_amd.parallel import CellPartitionedEngine
+        eng = CellPartitionedEngine(M, r, device=local_rank)
+        wh0 = synth.random_state(n, m, r, HYPER, seed=1003)
+        eng.set_state(wh0["lw"], wh0["lh"], wh0["eh"])
+        step = lambda: eng.step(HYPER)
+        units_per_step = 1
+        scaling = "strong"
+    else:
+        eng = C.VBEngine(M, r, device=local_rank)
+        wh0 = synth.random_state(n, m, r, HYPER, seed=1003 + rank)
+        eng.set_state(wh0["lw"], wh0["lh"], wh0["eh"])
+        step = lambda: eng.step(HYPER)
+        units_per_step = world
+        scaling = "weak"
+
+    # evidence of the first steps, kept for the match against the CPU restatement
+    ncheck = 0 if args.no_cpu else max(1, args.cpu_steps)
+    gpu_lk = []
+    for _ in range(args.warmup):
+        lkh, _ = step()
+        gpu_lk.append(lkh)
+
+    base_eng = getattr(eng, "engine", eng)
+    base_eng.timing_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        lkh, _ = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    sweep_ms, sweep_cnt = base_eng.timing_get()
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        bytes_iter, bytes_sweep = algorithmic_bytes(n, m, r, nnz)
+        value = units_per_step * args.steps / dt
+        sweep_s = (sweep_ms / max(sweep_cnt, 1)) * 1e-3
+        achieved = bytes_sweep / sweep_s / 1e9 if sweep_cnt else None
+        info = base_eng.layout_info()
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tpath) and not args.small:
+            try:
+                traffic = json.load(open(tpath)).get("sweep_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "VB-NMF update iterations/sec (20k x 50k sparse counts, rank 10)",
+            "value": value, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": scaling,
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": name, "n_genes": n, "n_cells": m, "nnz": nnz, "rank": r,
+                       "mode": args.mode if world > 1 else "single", "hyper": "fixed aw=bw=ah=bh=1",
+                       "lkh_last": lkh},
+            "roofline": {"bound": "hbm", "kernel": "k_sweep", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": bytes_sweep, "kernel_ms": sweep_s * 1e3,
+                         "streamed_bytes_per_launch": info["stream_bytes_per_step"]},
+            "iteration_roofline": {"bytes_iter": bytes_iter, "achieved_GBs": bytes_iter * (value / units_per_step) / 1e9,
+                                   "frac": bytes_iter * (value / units_per_step) / 1e9 / HBM_PEAK_GBS},
+        }
+        if not args.no_cpu and world == 1:
+            wh_cpu = synth.random_state(n, m, r, HYPER, seed=1003)
+            cb, cpu_lk = cpu_baseline(X, r, wh_cpu, ncheck)
+            out["cpu_baseline"] = cb
+            k = min(len(cpu_lk), len(gpu_lk))
+            if k:
+                out["elbo_rel_err_first_steps"] = max(abs(g / c - 1) for g, c in zip(gpu_lk[:k], cpu_lk[:k]))
+        print(json.dumps(out), flush=True)
+
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -23,30 +23,48 @@ def simulate_data(nfeatures, nsamples, nfactor=10, alpha0=0.5, shuffle=True, see
     if depth is None:
         depth = np.full(m, n * nfactor, dtype=np.int64)
     depth = np.asarray(depth, dtype=np.int64)
-    rows, cols = [], []
+    keys = []
     c0 = 0
+    perm = rng.permutation(m).astype(np.int64) if shuffle else np.arange(m, dtype=np.int64)
     for k, mk in enumerate(nsamples):
         q = rng.dirichlet(np.full(n, alpha0))
-        cdf = np.cumsum(q)
-        cdf[-1] = 1.0
         Lk = depth[c0:c0 + mk]
-        # multinomial draws by inverse-cdf on sum(L) uniforms: gene ids of every counted molecule
-        u = rng.random(int(Lk.sum()))
-        g = np.searchsorted(cdf, u, side="right").astype(np.int32)
-        np.minimum(g, n - 1, out=g)
-        c = np.repeat(np.arange(c0, c0 + mk, dtype=np.int32), Lk)
-        rows.append(g)
-        cols.append(c)
+        # Multinomial(L_j, q) for every cell of the cluster at once: the gene of each of the
+        # sum(L) molecules is iid ~ q, so draw the cluster's per-gene totals in one multinomial
+        # and deal the molecules to cells by a uniform shuffle (same law, O(n + sum L)).
+        tot = rng.multinomial(int(Lk.sum()), q)
+        g = np.repeat(np.arange(n, dtype=np.int64), tot)
+        rng.shuffle(g)
+        c = np.repeat(perm[c0:c0 + mk], Lk)
+        keys.append(c * n + g)                   # column-major linear index of each molecule
         c0 += mk
-    rows = np.concatenate(rows)
-    cols = np.concatenate(cols)
-    if shuffle:
-        perm = rng.permutation(m).astype(np.int32)
-        cols = perm[cols]
-    X = sp.coo_matrix((np.ones(rows.size, dtype=np.float64), (rows, cols)), shape=(n, m)).tocsc()
-    X.sum_duplicates()
-    X.sort_indices()
+    keys = np.concatenate(keys)
+    keys.sort()
+    first = np.flatnonzero(np.concatenate(([True], keys[1:] != keys[:-1])))
+    cnt = np.diff(np.concatenate((first, [keys.size]))).astype(np.float64)
+    uk = keys[first]
+    col = uk // n
+    row = (uk - col * n).astype(np.int32)
+    indptr = np.cumsum(np.bincount(col + 1, minlength=m + 1))
+    X = sp.csc_matrix((cnt, row, indptr.astype(np.int32)), shape=(n, m))
     return X if sparse else np.asfortranarray(X.toarray())
+
+
+def fill_empty(X, seed=0):
+    """Give every all-zero row / column one count at a random position, keeping the shape
+    (the other way to satisfy the reference's guards, R/bayesian.R:244-247)."""
+    rng = np.random.default_rng(seed)
+    X = sp.csc_matrix(X) if not sp.issparse(X) else X.tocsc()
+    n, m = X.shape
+    er = np.flatnonzero(np.asarray(X.sum(axis=1)).ravel() == 0)
+    ec = np.flatnonzero(np.asarray(X.sum(axis=0)).ravel() == 0)
+    if er.size == 0 and ec.size == 0:
+        return X
+    rows = np.concatenate((er, rng.integers(0, n, ec.size)))
+    cols = np.concatenate((rng.integers(0, m, er.size), ec))
+    X = (X + sp.csc_matrix((np.ones(rows.size), (rows, cols)), shape=(n, m))).tocsc()
+    X.sort_indices()
+    return X
 
 
 def drop_empty(X):
