@@ -35,6 +35,14 @@ struct Matrix {
 double sum_lgamma_x1(const Matrix &X, int64_t cb, int64_t ce);
 
 // ---- tiled device layout of one side (DESIGN.md "Data layout in HBM") ----
+//
+// A *task* is a run of at most `max_len` stored entries of one major (gene on side 0, cell
+// on side 1) whose minors fall in one minor block; one lane of the sweep kernel owns it.
+// Tasks of a block are sorted by length (descending) and cut into *slices* of 64 (one
+// wavefront); the slice list, ordered by block, is cut into `n_wg` contiguous ranges of
+// equal cost, one per persistent workgroup; a *segment* is a run of slices of one block
+// inside one workgroup's range (the workgroup stages that block of the gathered factor in
+// LDS once per segment).
 constexpr int kLanes = 64;          // one slice = one wavefront
 constexpr int kUnroll = 4;          // entries per lane per 16-byte load
 constexpr uint32_t kIdleLane = 0xFFFFFFFFu;
@@ -43,13 +51,17 @@ struct Layout {
     int side = 0;                   // 0: lanes own genes, minors = cells; 1: lanes own cells, minors = genes
     bool wide = false;
     int64_t n_major = 0, n_minor = 0;
-    int32_t block_width = 0, n_blocks = 0, chunk = 0;
-    int64_t n_tiles = 0, n_slices = 0, n_slots = 0, nnz = 0;
-    std::vector<int32_t> tile_block;
-    std::vector<int64_t> tile_slice0;    // n_tiles + 1
-    std::vector<uint32_t> slice_major;   // n_slices * 64
-    std::vector<int32_t> slice_width;    // n_slices
-    std::vector<int64_t> slice_off;      // n_slices
+    int32_t block_width = 0, n_blocks = 0, max_len = 0, n_wg = 0;
+    int64_t n_tasks = 0, n_slices = 0, n_slots = 0, n_segs = 0, nnz = 0;
+    std::vector<uint32_t> task_major;    // n_slices * 64 ; kIdleLane pads a block's last slice
+    std::vector<int32_t> slice_width;    // n_slices ; entries per lane, multiple of 4
+    std::vector<int64_t> slice_off;      // n_slices ; first slot of the slice
+    std::vector<int32_t> slice_block;    // n_slices ; minor block (host-side bookkeeping / tests)
+    std::vector<int32_t> seg_block;      // n_segs
+    std::vector<int32_t> seg_slice0;     // n_segs + 1
+    std::vector<int32_t> wg_seg0;        // n_wg + 1
+    std::vector<int32_t> inv_ptr;        // n_major + 1 : tasks of each major ...
+    std::vector<uint32_t> inv_task;      // n_tasks     : ... as slice*64+lane ids, in (block, position) order
     std::vector<uint32_t> packed;        // n_slots (wide == false)
     std::vector<uint32_t> wide_idx;      // n_slots (wide == true)
     std::vector<double> wide_val;        // n_slots (wide == true)
@@ -57,15 +69,16 @@ struct Layout {
 
 struct LayoutParams {
     int32_t block_width;   // minors per LDS block
-    int32_t chunk;         // majors per tile, multiple of 64
+    int32_t max_len;       // longest task (entries), multiple of 4
+    int32_t n_wg;          // persistent workgroups of the sweep kernel
 };
 
 // Padded rank used on the device (even, so a factor row is a whole number of 16-byte LDS reads).
 inline int padded_rank(int r) { return (r + 1) & ~1; }
-// Threads per workgroup of the sweep kernel at padded rank R (register budget: 128 VGPRs at 1024, 256 at 512).
+// Threads per workgroup of the sweep kernel at padded rank R.
 constexpr int sweep_threads(int R) { return R <= 4 ? 1024 : 512; }
-// Default block width / chunk for a side at padded rank R (LDS budget, tile count).
-LayoutParams default_layout_params(int64_t n_major, int64_t n_minor, int R);
+// Default block width / task length for a side at padded rank R; n_wg <= 0 picks the default (256).
+LayoutParams default_layout_params(int64_t n_major, int64_t n_minor, int R, int n_wg = 0);
 
 // Build the layout of `side` for columns [cb, ce) of X.
 int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const LayoutParams &lp, Layout &out);

@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -28,13 +29,13 @@ using namespace vbnmf;
 namespace {
 
 struct DeviceSide {
-    uint32_t *packed = nullptr, *widx = nullptr, *slice_major = nullptr;
+    uint32_t *packed = nullptr, *widx = nullptr, *task_major = nullptr, *inv_task = nullptr;
     double *wval = nullptr;
-    int32_t *slice_width = nullptr, *tile_block = nullptr;
-    int64_t *slice_off = nullptr, *tile_slice0 = nullptr;
+    int32_t *slice_width = nullptr, *seg_block = nullptr, *seg_slice0 = nullptr, *wg_seg0 = nullptr, *inv_ptr = nullptr;
+    int64_t *slice_off = nullptr;
     double *part = nullptr;
-    int64_t n_major = 0, n_minor = 0, n_tiles = 0, n_slices = 0, n_slots = 0;
-    int32_t block_width = 0, n_blocks = 0;
+    int64_t n_major = 0, n_minor = 0, n_tasks = 0, n_slices = 0, n_slots = 0;
+    int32_t block_width = 0, n_blocks = 0, n_wg = 0;
     bool wide = false;
 };
 
@@ -64,7 +65,7 @@ struct vbnmf_engine {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int64_t n = 0, m = 0, m_global = 0, nnz = 0;
-    int r = 0, R = 0, NT = 0;
+    int r = 0, R = 0, NT = 0, n_wg = 0;
     bool wide = false, partitioned = false;
     double lgx = 0.0;
     DeviceSide A, B;                  // A: lanes own genes ; B: lanes own cells
@@ -91,44 +92,47 @@ namespace {
 
 void free_side(DeviceSide &S)
 {
-    (void)hipFree(S.packed); (void)hipFree(S.widx); (void)hipFree(S.wval); (void)hipFree(S.slice_major);
-    (void)hipFree(S.slice_width); (void)hipFree(S.tile_block); (void)hipFree(S.slice_off);
-    (void)hipFree(S.tile_slice0); (void)hipFree(S.part);
+    (void)hipFree(S.packed); (void)hipFree(S.widx); (void)hipFree(S.wval); (void)hipFree(S.task_major);
+    (void)hipFree(S.inv_task); (void)hipFree(S.slice_width); (void)hipFree(S.seg_block); (void)hipFree(S.seg_slice0);
+    (void)hipFree(S.wg_seg0); (void)hipFree(S.inv_ptr); (void)hipFree(S.slice_off); (void)hipFree(S.part);
     S = DeviceSide();
 }
 
 int upload_side(const Layout &L, int R, DeviceSide &S)
 {
-    S.n_major = L.n_major; S.n_minor = L.n_minor; S.n_tiles = L.n_tiles; S.n_slices = L.n_slices;
-    S.n_slots = L.n_slots; S.block_width = L.block_width; S.n_blocks = L.n_blocks; S.wide = L.wide;
+    S.n_major = L.n_major; S.n_minor = L.n_minor; S.n_tasks = L.n_tasks; S.n_slices = L.n_slices;
+    S.n_slots = L.n_slots; S.block_width = L.block_width; S.n_blocks = L.n_blocks; S.n_wg = L.n_wg; S.wide = L.wide;
     if (L.wide) {
         if (int rc = dev_upload(&S.widx, L.wide_idx)) return rc;
         if (int rc = dev_upload(&S.wval, L.wide_val)) return rc;
     } else {
         if (int rc = dev_upload(&S.packed, L.packed)) return rc;
     }
-    if (int rc = dev_upload(&S.slice_major, L.slice_major)) return rc;
+    if (int rc = dev_upload(&S.task_major, L.task_major)) return rc;
     if (int rc = dev_upload(&S.slice_width, L.slice_width)) return rc;
     if (int rc = dev_upload(&S.slice_off, L.slice_off)) return rc;
-    if (int rc = dev_upload(&S.tile_block, L.tile_block)) return rc;
-    if (int rc = dev_upload(&S.tile_slice0, L.tile_slice0)) return rc;
-    if (int rc = dev_alloc(&S.part, (size_t)L.n_blocks * L.n_major * R)) return rc;
+    if (int rc = dev_upload(&S.seg_block, L.seg_block)) return rc;
+    if (int rc = dev_upload(&S.seg_slice0, L.seg_slice0)) return rc;
+    if (int rc = dev_upload(&S.wg_seg0, L.wg_seg0)) return rc;
+    if (int rc = dev_upload(&S.inv_ptr, L.inv_ptr)) return rc;
+    if (int rc = dev_upload(&S.inv_task, L.inv_task)) return rc;
+    if (int rc = dev_alloc(&S.part, (size_t)L.n_slices * kLanes * R)) return rc;
     return VBNMF_OK;
 }
 
-SweepSide sweep_side(const vbnmf_engine *e, const DeviceSide &S, bool gene_side, double *epart)
+SweepSide sweep_side_args(const vbnmf_engine *e, const DeviceSide &S, bool gene_side, double *epart)
 {
     SweepSide P;
     P.packed = S.packed; P.widx = S.widx; P.wval = S.wval;
-    P.slice_major = S.slice_major; P.slice_width = S.slice_width; P.slice_off = S.slice_off;
-    P.tile_block = S.tile_block; P.tile_slice0 = S.tile_slice0;
+    P.task_major = S.task_major; P.slice_width = S.slice_width; P.slice_off = S.slice_off;
+    P.seg_block = S.seg_block; P.seg_slice0 = S.seg_slice0; P.wg_seg0 = S.wg_seg0;
     P.F = gene_side ? e->lw : e->lh;
     P.llF = gene_side ? e->llw : e->llh;
     P.G = gene_side ? e->lh : e->lw;
     P.part = S.part; P.epart = epart;
-    P.n_major = S.n_major; P.n_minor = (int32_t)S.n_minor; P.block_width = S.block_width;
+    P.n_minor = (int32_t)S.n_minor; P.block_width = S.block_width;
     P.logterm = gene_side ? 1 : 0;
-    P.n_tiles = (int32_t)S.n_tiles;
+    P.n_wg = S.n_wg;
     return P;
 }
 
@@ -144,7 +148,7 @@ int launch_sweep_t(vbnmf_engine *e, const SweepSide &a, const SweepSide &b)
     } else if (e->device >= 16) {
         HIPCHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
-    const unsigned grid = (unsigned)(a.n_tiles + b.n_tiles);
+    const unsigned grid = (unsigned)e->n_wg;
     hipLaunchKernelGGL((k_sweep<R, WIDE, NT>), dim3(grid), dim3(NT), e->lds_bytes, e->stream, a, b);
     HIPCHECK(hipGetLastError());
     return VBNMF_OK;
@@ -162,8 +166,8 @@ int launch_sweep_r(vbnmf_engine *e, const SweepSide &a, const SweepSide &b)
 
 int launch_sweep(vbnmf_engine *e)
 {
-    SweepSide a = sweep_side(e, e->A, true, e->epart);
-    SweepSide b = sweep_side(e, e->B, false, e->epart + e->A.n_slices);
+    SweepSide a = sweep_side_args(e, e->A, true, e->epart);
+    SweepSide b = sweep_side_args(e, e->B, false, e->epart + e->A.n_slices);
     if (e->timing) { HIPCHECK(hipEventRecord(e->ev0, e->stream)); }
     int rc = VBNMF_ERR_BAD_ARG;
     switch (e->R) {
@@ -181,7 +185,8 @@ int launch_update(vbnmf_engine *e, bool gene_side, double a, double b, double fu
 {
     const double lga = -std::lgamma(a) + a * std::log(a / b);     // reference :82 / :87
     const double *acc = gene_side ? e->red : e->B.part;
-    const int nacc = gene_side ? 1 : e->B.n_blocks;
+    const int32_t *inv_ptr = gene_side ? nullptr : e->B.inv_ptr;
+    const uint32_t *inv_task = gene_side ? nullptr : e->B.inv_task;
     const int64_t nmaj = gene_side ? e->n : e->m;
     const double *other = gene_side ? e->red + (size_t)e->n * e->R : e->outW;
     double *l = gene_side ? e->lw : e->lh, *ll = gene_side ? e->llw : e->llh;
@@ -189,7 +194,7 @@ int launch_update(vbnmf_engine *e, bool gene_side, double a, double b, double fu
     double *bp = gene_side ? e->bpW : e->bpH;
     const unsigned grid = (unsigned)(gene_side ? e->nbW : e->nbH);
     switch (e->R) {
-#define X(RR) case RR: hipLaunchKernelGGL((k_update<RR>), dim3(grid), dim3(256), 0, e->stream, acc, nacc, nmaj, e->r, other, a, b, lga, fudge, l, ll, ev, d, bp); break;
+#define X(RR) case RR: hipLaunchKernelGGL((k_update<RR>), dim3(grid), dim3(256), 0, e->stream, acc, inv_ptr, inv_task, nmaj, e->r, other, a, b, lga, fudge, l, ll, ev, d, bp); break;
         VBNMF_FOR_EACH_R(X)
 #undef X
         default: return fail(VBNMF_ERR_BAD_ARG, "unsupported padded rank %d", e->R);
@@ -243,7 +248,7 @@ int launch_reduce_w(vbnmf_engine *e)
 int launch_pack(vbnmf_engine *e)
 {
     const int64_t cnt = e->n * e->R;
-    hipLaunchKernelGGL(k_pack, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, e->stream, e->A.part, e->A.n_blocks, cnt, e->red);
+    hipLaunchKernelGGL(k_pack, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, e->stream, e->A.part, e->A.inv_ptr, e->A.inv_task, e->n, e->R, e->red);
     HIPCHECK(hipGetLastError());
     double *tail = e->red + cnt;
     ReduceArgs a{};
@@ -330,6 +335,12 @@ int vbnmf_engine_create_part(const vbnmf_matrix *X, int64_t cb, int64_t ce, int6
     if (int rc = check_device(device)) return rc;
     HIPCHECK(hipSetDevice(device));
 
+    int n_cu = 256;
+    {
+        hipDeviceProp_t prop;
+        HIPCHECK(hipGetDeviceProperties(&prop, device));
+        if (prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
+    }
     vbnmf_engine *e = new (std::nothrow) vbnmf_engine();
     if (!e) return fail(VBNMF_ERR_OOM, "out of host memory");
     e->device = device;
@@ -337,6 +348,8 @@ int vbnmf_engine_create_part(const vbnmf_matrix *X, int64_t cb, int64_t ce, int6
     e->r = r; e->R = padded_rank(r);
     e->NT = sweep_threads(e->R);
     e->wide = !X->M.counts_u16;
+    e->n_wg = n_cu;                      // one persistent workgroup per CU
+    if (const char *sv = getenv("VBNMF_NWG")) { int v = atoi(sv); if (v > 0) e->n_wg = v; }
     e->partitioned = (ce - cb) != m_global;
     int rc = VBNMF_OK;
     auto bail = [&](int code) { vbnmf_engine_destroy(e); return code; };
@@ -345,7 +358,7 @@ int vbnmf_engine_create_part(const vbnmf_matrix *X, int64_t cb, int64_t ce, int6
         for (int side = 0; side < 2 && !rc; side++) {
             Layout L;
             int64_t nmaj = side == 0 ? e->n : e->m, nmin = side == 0 ? e->m : e->n;
-            LayoutParams lp = default_layout_params(nmaj, nmin, e->R);
+            LayoutParams lp = default_layout_params(nmaj, nmin, e->R, e->n_wg);
             rc = build_layout(X->M, cb, ce, side, lp, L);
             if (!rc) rc = upload_side(L, e->R, side == 0 ? e->A : e->B);
             if (side == 0) e->nnz = L.nnz;
@@ -573,8 +586,8 @@ int vbnmf_engine_layout_info(const vbnmf_engine *e, int64_t *nnz, int64_t *slots
     if (slots_gene) *slots_gene = e->A.n_slots;
     if (slots_cell) *slots_cell = e->B.n_slots;
     if (stream_bytes) *stream_bytes = (e->A.n_slots + e->B.n_slots) * (int64_t)(e->wide ? 12 : 4);
-    if (tiles_gene) *tiles_gene = e->A.n_tiles;
-    if (tiles_cell) *tiles_cell = e->B.n_tiles;
+    if (tiles_gene) *tiles_gene = e->A.n_tasks;
+    if (tiles_cell) *tiles_cell = e->B.n_tasks;
     return VBNMF_OK;
 }
 

@@ -243,7 +243,7 @@ static int env_int(const char *name, int dflt)
     return atoi(s);
 }
 
-LayoutParams default_layout_params(int64_t n_major, int64_t n_minor, int R)
+LayoutParams default_layout_params(int64_t n_major, int64_t n_minor, int R, int n_wg)
 {
     (void)n_major;
     LayoutParams lp;
@@ -260,17 +260,19 @@ LayoutParams default_layout_params(int64_t n_major, int64_t n_minor, int R)
     c = (c + 7) & ~(int64_t)7;
     if (c > cmax) c = cmax;
     lp.block_width = (int32_t)c;
-    int chunk = env_int("VBNMF_CHUNK", 0);
-    if (chunk <= 0) chunk = sweep_threads(R);          // one slice per wave of the sweep workgroup
-    chunk = (chunk + 63) & ~63;
-    lp.chunk = chunk;
+    int ml = env_int("VBNMF_MAX_LEN", 256);
+    if (ml < kUnroll) ml = kUnroll;
+    lp.max_len = (ml + kUnroll - 1) / kUnroll * kUnroll;
+    if (n_wg <= 0) n_wg = env_int("VBNMF_NWG", 256);
+    if (n_wg < 1) n_wg = 1;
+    lp.n_wg = n_wg;
     return lp;
 }
 
 int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const LayoutParams &lp, Layout &L)
 {
     if (cb < 0 || ce > X.m || cb >= ce) return fail(VBNMF_ERR_BAD_ARG, "column range [%lld, %lld) is outside the matrix", (long long)cb, (long long)ce);
-    if (lp.block_width <= 0 || lp.block_width > 65536 || lp.chunk <= 0 || lp.chunk % kLanes)
+    if (lp.block_width <= 0 || lp.block_width > 65536 || lp.max_len <= 0 || lp.max_len % kUnroll || lp.n_wg <= 0)
         return fail(VBNMF_ERR_BAD_ARG, "bad layout parameters");
 
     // major-compressed view of X[:, cb:ce)
@@ -280,27 +282,23 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
     const int64_t *ptr;
     const int32_t *idx;
     const double *val;
-    int64_t base;                 // ptr values are absolute positions into idx/val minus `base`
     if (side == 1) {
         L.n_major = ce - cb; L.n_minor = X.n;
-        ptr = X.colptr.data() + cb; idx = X.row.data(); val = X.val.data(); base = 0;
+        ptr = X.colptr.data() + cb; idx = X.row.data(); val = X.val.data();
     } else {
         L.n_major = X.n; L.n_minor = ce - cb;
         transpose_compressed(ce - cb, X.n, X.colptr.data() + cb, X.row.data(), X.val.data(), 0, tptr, tidx, tval);
-        // transpose_compressed numbers the outer vectors from 0, i.e. local cell ids already
-        ptr = tptr.data(); idx = tidx.data(); val = tval.data(); base = 0;
-        (void)base;
+        ptr = tptr.data(); idx = tidx.data(); val = tval.data();
     }
     L.side = side;
     L.wide = !X.counts_u16;
     L.block_width = lp.block_width;
-    L.chunk = lp.chunk;
+    L.max_len = lp.max_len;
+    L.n_wg = lp.n_wg;
     const int64_t nmaj = L.n_major;
     const int32_t C = L.block_width;
     const int32_t nblk = (int32_t)((L.n_minor + C - 1) / C);
-    const int64_t nchunk = (nmaj + L.chunk - 1) / L.chunk;
     L.n_blocks = nblk;
-    L.n_tiles = nchunk * nblk;
     L.nnz = ptr[nmaj] - ptr[0];
 
     // bpos[major][b] = position of the major's first entry whose minor is in block >= b
@@ -317,65 +315,116 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
         }
     });
 
-    // per tile: majors sorted by their entry count in the tile (descending, ties by id), cut in slices of 64
-    struct TileTmp { std::vector<uint32_t> lanes; std::vector<int32_t> widths; int64_t slots = 0; };
-    std::vector<TileTmp> tmp(L.n_tiles);
-    parallel_for(L.n_tiles, [&](int64_t b, int64_t e, int) {
-        std::vector<std::pair<int64_t, uint32_t>> ord;
-        for (int64_t t = b; t < e; t++) {
-            int64_t c = t / nblk;
-            int32_t blk = (int32_t)(t % nblk);
-            int64_t m0 = c * L.chunk, m1 = std::min(nmaj, m0 + L.chunk);
-            ord.clear();
-            for (int64_t M = m0; M < m1; M++) {
+    // tasks per block: (major, block) runs longer than max_len are cut in near-equal pieces
+    struct Task { uint32_t major; int32_t len; int64_t pos; };
+    std::vector<std::vector<Task>> btasks(nblk);
+    parallel_for(nblk, [&](int64_t b0, int64_t b1, int) {
+        for (int64_t blk = b0; blk < b1; blk++) {
+            std::vector<Task> &T = btasks[blk];
+            for (int64_t M = 0; M < nmaj; M++) {
                 const int64_t *bp = &bpos[(size_t)M * (nblk + 1)];
-                ord.emplace_back(bp[blk + 1] - bp[blk], (uint32_t)M);
+                int64_t q0 = bp[blk], cnt = bp[blk + 1] - q0;
+                if (cnt <= 0) continue;
+                int64_t pieces = (cnt + lp.max_len - 1) / lp.max_len;
+                for (int64_t pc = 0; pc < pieces; pc++) {
+                    int64_t s = cnt * pc / pieces, t = cnt * (pc + 1) / pieces;
+                    T.push_back({(uint32_t)M, (int32_t)(t - s), q0 + s});
+                }
             }
-            std::sort(ord.begin(), ord.end(), [](const std::pair<int64_t, uint32_t> &a, const std::pair<int64_t, uint32_t> &c2) {
-                return a.first != c2.first ? a.first > c2.first : a.second < c2.second;
-            });
-            TileTmp &T = tmp[t];
-            int64_t nsl = ((m1 - m0) + kLanes - 1) / kLanes;
-            T.lanes.assign(nsl * kLanes, kIdleLane);
-            T.widths.assign(nsl, 0);
-            for (size_t q = 0; q < ord.size(); q++) T.lanes[q] = ord[q].second;
-            for (int64_t s = 0; s < nsl; s++) {
-                int64_t w = ord[s * kLanes].first;            // sorted: the slice's first lane is its longest
-                w = (w + kUnroll - 1) / kUnroll * kUnroll;
-                T.widths[s] = (int32_t)w;
-                T.slots += w * kLanes;
-            }
+            std::stable_sort(T.begin(), T.end(), [](const Task &a, const Task &c2) { return a.len > c2.len; });
         }
     });
 
-    // heaviest tiles first (the dispatcher hands workgroups out in index order)
-    std::vector<int64_t> order(L.n_tiles);
-    std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t c) { return tmp[a].slots > tmp[c].slots; });
-
-    L.tile_block.resize(L.n_tiles);
-    L.tile_slice0.assign(L.n_tiles + 1, 0);
-    for (int64_t o = 0; o < L.n_tiles; o++) {
-        int64_t t = order[o];
-        L.tile_block[o] = (int32_t)(t % nblk);
-        L.tile_slice0[o + 1] = L.tile_slice0[o] + (int64_t)tmp[t].widths.size();
-    }
-    L.n_slices = L.tile_slice0[L.n_tiles];
-    L.slice_major.resize((size_t)L.n_slices * kLanes);
-    L.slice_width.resize(L.n_slices);
-    L.slice_off.resize(L.n_slices);
-    int64_t off = 0;
-    for (int64_t o = 0; o < L.n_tiles; o++) {
-        const TileTmp &T = tmp[order[o]];
-        int64_t s0 = L.tile_slice0[o];
-        for (size_t s = 0; s < T.widths.size(); s++) {
-            L.slice_width[s0 + s] = T.widths[s];
-            L.slice_off[s0 + s] = off;
-            off += (int64_t)T.widths[s] * kLanes;
+    // slices: 64 consecutive tasks of a block; blocks in index order
+    std::vector<int64_t> bslice0(nblk + 1, 0);
+    for (int32_t blk = 0; blk < nblk; blk++)
+        bslice0[blk + 1] = bslice0[blk] + ((int64_t)btasks[blk].size() + kLanes - 1) / kLanes;
+    L.n_slices = bslice0[nblk];
+    if (L.n_slices > 0x7FFFFFF0LL / kLanes) return fail(VBNMF_ERR_BAD_ARG, "too many tasks for 32-bit task ids");
+    L.task_major.assign((size_t)L.n_slices * kLanes, kIdleLane);
+    L.slice_width.assign(L.n_slices, 0);
+    L.slice_off.assign(L.n_slices, 0);
+    L.slice_block.assign(L.n_slices, 0);
+    std::vector<int64_t> task_pos((size_t)L.n_slices * kLanes, 0);
+    std::vector<int32_t> task_len((size_t)L.n_slices * kLanes, 0);
+    L.n_tasks = 0;
+    for (int32_t blk = 0; blk < nblk; blk++) {
+        const std::vector<Task> &T = btasks[blk];
+        L.n_tasks += (int64_t)T.size();
+        for (size_t q = 0; q < T.size(); q++) {
+            size_t id = (size_t)bslice0[blk] * kLanes + q;
+            L.task_major[id] = T[q].major; task_pos[id] = T[q].pos; task_len[id] = T[q].len;
         }
-        std::memcpy(&L.slice_major[(size_t)s0 * kLanes], T.lanes.data(), T.lanes.size() * sizeof(uint32_t));
+        for (int64_t s = bslice0[blk]; s < bslice0[blk + 1]; s++) {
+            int32_t w = task_len[(size_t)s * kLanes];            // sorted: first lane is the longest
+            L.slice_width[s] = (w + kUnroll - 1) / kUnroll * kUnroll;
+            L.slice_block[s] = blk;
+        }
     }
+    btasks.clear();
+    int64_t off = 0;
+    for (int64_t s = 0; s < L.n_slices; s++) { L.slice_off[s] = off; off += (int64_t)L.slice_width[s] * kLanes; }
     L.n_slots = off;
+
+    // inverse index: the tasks of each major in (block, position) order -- the fixed order in
+    // which their partial statistics are summed
+    L.inv_ptr.assign(nmaj + 1, 0);
+    for (size_t id = 0; id < L.task_major.size(); id++)
+        if (L.task_major[id] != kIdleLane) L.inv_ptr[L.task_major[id] + 1]++;
+    for (int64_t M = 0; M < nmaj; M++) L.inv_ptr[M + 1] += L.inv_ptr[M];
+    L.inv_task.assign(L.n_tasks, 0);
+    {
+        std::vector<std::pair<int64_t, uint32_t>> tmp;     // (position, id) per major
+        std::vector<int32_t> cur(L.inv_ptr.begin(), L.inv_ptr.end() - 1);
+        std::vector<int64_t> key(L.n_tasks);
+        for (size_t id = 0; id < L.task_major.size(); id++) {
+            uint32_t M = L.task_major[id];
+            if (M == kIdleLane) continue;
+            int32_t o = cur[M]++;
+            L.inv_task[o] = (uint32_t)id; key[o] = task_pos[id];
+        }
+        parallel_for(nmaj, [&](int64_t b, int64_t e, int) {
+            std::vector<std::pair<int64_t, uint32_t>> t2;
+            for (int64_t M = b; M < e; M++) {
+                int32_t s = L.inv_ptr[M], t = L.inv_ptr[M + 1];
+                if (t - s < 2) continue;
+                t2.clear();
+                for (int32_t q = s; q < t; q++) t2.emplace_back(key[q], L.inv_task[q]);
+                std::sort(t2.begin(), t2.end());
+                for (int32_t q = s; q < t; q++) L.inv_task[q] = t2[q - s].second;
+            }
+        });
+    }
+
+    // persistent workgroups: contiguous slice ranges of equal cost; segments = runs of one block
+    {
+        const double c0 = 8.0;                               // per-slice overhead in entry-equivalents
+        std::vector<double> pre(L.n_slices + 1, 0.0);
+        for (int64_t s = 0; s < L.n_slices; s++) pre[s + 1] = pre[s] + L.slice_width[s] + c0;
+        const double total = pre[L.n_slices];
+        L.wg_seg0.assign(L.n_wg + 1, 0);
+        L.seg_block.clear();
+        L.seg_slice0.clear();
+        int64_t s = 0;
+        for (int w = 0; w < L.n_wg; w++) {
+            L.wg_seg0[w] = (int32_t)L.seg_block.size();
+            const double lim = total * (w + 1) / L.n_wg;
+            int64_t e = s;
+            if (w == L.n_wg - 1) e = L.n_slices;
+            else while (e < L.n_slices && 0.5 * (pre[e] + pre[e + 1]) <= lim) e++;
+            while (s < e) {                                   // cut [s, e) at block changes
+                int64_t t = s;
+                while (t < e && L.slice_block[t] == L.slice_block[s]) t++;
+                L.seg_block.push_back(L.slice_block[s]);
+                L.seg_slice0.push_back((int32_t)s);
+                s = t;
+            }
+        }
+        L.wg_seg0[L.n_wg] = (int32_t)L.seg_block.size();
+        L.seg_slice0.push_back((int32_t)L.n_slices);
+        L.n_segs = (int64_t)L.seg_block.size();
+    }
+
     try {
         if (L.wide) { L.wide_idx.assign(L.n_slots, 0u); L.wide_val.assign(L.n_slots, 0.0); }
         else L.packed.assign(L.n_slots, 0u);
@@ -384,23 +433,19 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
     }
 
     // fill: slot(t, lane) = off + (t/4)*256 + lane*4 + t%4 ; padding slots stay {minor 0, value 0}
-    parallel_for(L.n_tiles, [&](int64_t b, int64_t e, int) {
-        for (int64_t o = b; o < e; o++) {
-            int32_t blk = L.tile_block[o];
-            int32_t m0 = blk * C;
-            for (int64_t s = L.tile_slice0[o]; s < L.tile_slice0[o + 1]; s++) {
-                int64_t so = L.slice_off[s];
-                for (int lane = 0; lane < kLanes; lane++) {
-                    uint32_t M = L.slice_major[(size_t)s * kLanes + lane];
-                    if (M == kIdleLane) continue;
-                    const int64_t *bp = &bpos[(size_t)M * (nblk + 1)];
-                    int64_t q0 = bp[blk], cnt = bp[blk + 1] - q0;
-                    for (int64_t t = 0; t < cnt; t++) {
-                        int64_t slot = so + (t / kUnroll) * (kLanes * kUnroll) + lane * kUnroll + (t % kUnroll);
-                        uint32_t local = (uint32_t)(idx[q0 + t] - m0);
-                        if (L.wide) { L.wide_idx[slot] = local; L.wide_val[slot] = val[q0 + t]; }
-                        else L.packed[slot] = ((uint32_t)val[q0 + t] << 16) | local;
-                    }
+    parallel_for(L.n_slices, [&](int64_t b, int64_t e, int) {
+        for (int64_t s = b; s < e; s++) {
+            const int32_t m0 = L.slice_block[s] * C;
+            const int64_t so = L.slice_off[s];
+            for (int lane = 0; lane < kLanes; lane++) {
+                size_t id = (size_t)s * kLanes + lane;
+                if (L.task_major[id] == kIdleLane) continue;
+                const int64_t q0 = task_pos[id];
+                for (int64_t t = 0; t < task_len[id]; t++) {
+                    int64_t slot = so + (t / kUnroll) * (kLanes * kUnroll) + lane * kUnroll + (t % kUnroll);
+                    uint32_t local = (uint32_t)(idx[q0 + t] - m0);
+                    if (L.wide) { L.wide_idx[slot] = local; L.wide_val[slot] = val[q0 + t]; }
+                    else L.packed[slot] = ((uint32_t)val[q0 + t] << 16) | local;
                 }
             }
         }
@@ -521,11 +566,12 @@ int vbnmf_layout_build(const vbnmf_matrix *X, int64_t col_begin, int64_t col_end
     const Layout &L = H->L;
     view->side = L.side; view->wide = L.wide ? 1 : 0;
     view->n_major = L.n_major; view->n_minor = L.n_minor;
-    view->block_width = L.block_width; view->n_blocks = L.n_blocks; view->chunk = L.chunk;
-    view->n_tiles = L.n_tiles; view->n_slices = L.n_slices; view->n_slots = L.n_slots;
-    view->tile_block = L.tile_block.data(); view->tile_slice0 = L.tile_slice0.data();
-    view->slice_major = L.slice_major.data(); view->slice_width = L.slice_width.data();
-    view->slice_off = L.slice_off.data();
+    view->block_width = L.block_width; view->n_blocks = L.n_blocks; view->max_len = L.max_len; view->n_wg = L.n_wg;
+    view->n_tasks = L.n_tasks; view->n_slices = L.n_slices; view->n_slots = L.n_slots; view->n_segs = L.n_segs;
+    view->task_major = L.task_major.data(); view->slice_width = L.slice_width.data();
+    view->slice_off = L.slice_off.data(); view->slice_block = L.slice_block.data();
+    view->seg_block = L.seg_block.data(); view->seg_slice0 = L.seg_slice0.data(); view->wg_seg0 = L.wg_seg0.data();
+    view->inv_ptr = L.inv_ptr.data(); view->inv_task = L.inv_task.data();
     view->packed = L.wide ? nullptr : L.packed.data();
     view->wide_idx = L.wide ? L.wide_idx.data() : nullptr;
     view->wide_val = L.wide ? L.wide_val.data() : nullptr;

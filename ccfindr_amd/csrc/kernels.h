@@ -27,31 +27,74 @@ namespace vbnmf {
 constexpr uint32_t kIdle = 0xFFFFFFFFu;
 
 // ------------------------------------------------------------------------------------
-// Sweep: one workgroup per tile = (chunk of majors) x (block of minors).  The minor
-// block of the gathered factor G sits in LDS; each lane owns one major (its factor row
-// F and R accumulators live in VGPRs) and walks that major's entries in the tile, which
-// are stored lane-interleaved so a wave reads 1 KiB per load instruction.
+// Sweep.  256 persistent workgroups; each walks its cost-balanced range of slices, first of
+// the gene side then of the cell side.  Within a segment (slices of one minor block) that
+// block of the gathered factor G sits in LDS; each lane owns one task (a run of one
+// major's entries): the major's factor row F and R accumulators live in VGPRs, the entries
+// are stored lane-interleaved so a wave reads 1 KiB per load instruction, and the partial
+// statistics are written task-major (a wave writes one contiguous 64*R*8-byte piece).
 // ------------------------------------------------------------------------------------
 struct SweepSide {
     const uint32_t *packed;        // (count << 16) | local minor          (packed layout)
     const uint32_t *widx;          // local minor                           (wide layout)
     const double *wval;            // value                                 (wide layout)
-    const uint32_t *slice_major;   // [n_slices][64]
+    const uint32_t *task_major;    // [n_slices][64]
     const int32_t *slice_width;    // [n_slices]
     const int64_t *slice_off;      // [n_slices]
-    const int32_t *tile_block;     // [n_tiles]
-    const int64_t *tile_slice0;    // [n_tiles + 1]
+    const int32_t *seg_block;      // [n_segs]
+    const int32_t *seg_slice0;     // [n_segs + 1]
+    const int32_t *wg_seg0;        // [n_wg + 1]
     const double *F;               // [n_major][R]  factor owned by the lanes
     const double *llF;             // [n_major][R]  F * log F
     const double *G;               // [n_minor][R]  factor gathered through LDS
-    double *part;                  // [n_blocks][n_major][R]
+    double *part;                  // [n_slices*64][R] partial statistics per task
     double *epart;                 // [n_slices] evidence partials
-    int64_t n_major;
     int32_t n_minor;
     int32_t block_width;
     int32_t logterm;               // this side also accumulates sum x*log(wth)
-    int32_t n_tiles;
+    int32_t n_wg;
 };
+
+// ln(x) for finite x > 0 (also subnormal); x == 0 gives -inf, NaN propagates.  The
+// argument reduction and degree-7 minimax polynomial in s^2, s = f/(2+f), are the
+// classical ones (x = 2^k (1+f), sqrt(1/2) <= 1+f < sqrt(2)); < 1 ulp, checked against
+// mpmath in tests.  Branch-free so the sweep's inner loop stays one basic block
+// (ocml's log costs ~95 instructions in double-double; this is ~35).
+__device__ __forceinline__ double dev_log(double x)
+{
+    int k = __builtin_amdgcn_frexp_exp(x);
+    double m = __builtin_amdgcn_frexp_mant(x);            // [0.5, 1)
+    const bool lo = m < 0.70710678118654752440;
+    m = lo ? m + m : m;
+    k = lo ? k - 1 : k;
+    const double f = m - 1.0;
+    const double d = 2.0 + f;
+    double rc = __builtin_amdgcn_rcp(d);
+    rc = fma(fma(-d, rc, 1.0), rc, rc);
+    rc = fma(fma(-d, rc, 1.0), rc, rc);
+    double s = f * rc;
+    s = fma(fma(-d, s, f), rc, s);
+    const double z = s * s, w = z * z;
+    const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+    const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01), 6.666666666666735130e-01);
+    const double Rp = t1 + t2;
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)k;
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    double res = dk * ln2_hi - ((hfsq - (s * (hfsq + Rp) + dk * ln2_lo)) - f);
+    return x == 0.0 ? -__builtin_inf() : res;
+}
+
+// x / w for finite w of ordinary magnitude: reciprocal seed, two Newton steps, one residual
+// correction (no range scaling: wth = sum_k lw*lh is far from the exponent limits).
+__device__ __forceinline__ double dev_div(double x, double w)
+{
+    double rc = __builtin_amdgcn_rcp(w);
+    rc = fma(fma(-w, rc, 1.0), rc, rc);
+    rc = fma(fma(-w, rc, 1.0), rc, rc);
+    const double q = x * rc;
+    return fma(fma(-w, q, x), rc, q);
+}
 
 template <int R>
 struct SweepRegs {
@@ -61,115 +104,150 @@ struct SweepRegs {
 };
 
 template <int R>
-__device__ __forceinline__ void sweep_entry(SweepRegs<R> &S, const double2 *__restrict__ ldsG, uint32_t idx,
-                                            double x, bool live, bool logterm)
+__device__ __forceinline__ void lds_row(const double2 *__restrict__ ldsG, uint32_t idx, double2 (&gv)[R / 2])
 {
     const double2 *g = ldsG + idx * (R / 2);
-    double2 gv[R / 2];
 #pragma unroll
     for (int kk = 0; kk < R / 2; kk++) gv[kk] = g[kk];
+}
+
+// One stored entry: wth = F . g ; q = x / wth ; acc += q g ; lsum += x log(wth).
+// Padding slots have x = 0 and are computed on wth := 1 so they add exact zeros.
+template <int R>
+__device__ __forceinline__ void sweep_entry(SweepRegs<R> &S, const double2 (&gv)[R / 2], double x, bool live, bool logterm)
+{
     double wth = 0.0;
 #pragma unroll
     for (int kk = 0; kk < R / 2; kk++) {
         wth = fma(S.F[2 * kk], gv[kk].x, wth);
         wth = fma(S.F[2 * kk + 1], gv[kk].y, wth);
     }
-    const double q = live ? x / wth : 0.0;
+    wth = live ? wth : 1.0;
+    const double q = dev_div(x, wth);
 #pragma unroll
     for (int kk = 0; kk < R / 2; kk++) {
         S.acc[2 * kk] = fma(q, gv[kk].x, S.acc[2 * kk]);
         S.acc[2 * kk + 1] = fma(q, gv[kk].y, S.acc[2 * kk + 1]);
     }
-    if (logterm) S.lsum = fma(x, live ? log(wth) : 0.0, S.lsum);
+    if (logterm) S.lsum = fma(x, dev_log(wth), S.lsum);
+}
+
+template <int R, bool WIDE, bool LOGTERM, int NT>
+__device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restrict__ ldsG)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // workgroups that share an XCD (blockIdx % 8) take neighbouring ranges, i.e. mostly the same blocks
+    const int nwg = S.n_wg;
+    const int wg = (nwg % 8 == 0) ? (int)(blockIdx.x % 8) * (nwg / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+    const int seg0 = S.wg_seg0[wg], seg1 = S.wg_seg0[wg + 1];
+    for (int seg = seg0; seg < seg1; seg++) {
+        const int blk = S.seg_block[seg];
+        const int m0 = blk * S.block_width;
+        const int cw = min(S.block_width, S.n_minor - m0);
+        __syncthreads();                                   // readers of the previous block are done
+        {
+            const double2 *G2 = reinterpret_cast<const double2 *>(S.G + (size_t)m0 * R);
+            const int cnt = cw * (R / 2);
+            for (int t = threadIdx.x; t < cnt; t += NT) ldsG[t] = G2[t];
+        }
+        __syncthreads();
+        const int s0 = S.seg_slice0[seg], s1 = S.seg_slice0[seg + 1];
+        for (int s = s0 + wave; s < s1; s += NT / 64) {
+            const uint32_t M = S.task_major[(size_t)s * 64 + lane];
+            const int ng = S.slice_width[s] >> 2;
+            const int64_t off = S.slice_off[s];
+            SweepRegs<R> T;
+            if (M != kIdle) {
+                const double2 *F2 = reinterpret_cast<const double2 *>(S.F + (size_t)M * R);
+#pragma unroll
+                for (int kk = 0; kk < R / 2; kk++) { double2 v = F2[kk]; T.F[2 * kk] = v.x; T.F[2 * kk + 1] = v.y; }
+            } else {
+#pragma unroll
+                for (int k = 0; k < R; k++) T.F[k] = 1.0;   // idle lane: only sees padding slots
+            }
+#pragma unroll
+            for (int k = 0; k < R; k++) T.acc[k] = 0.0;
+            T.lsum = 0.0;
+
+            if (!WIDE) {
+                const uint4 *E = reinterpret_cast<const uint4 *>(S.packed + off) + lane;
+                uint4 e = E[0];                                           // every slice has ng >= 1
+                double2 g0[R / 2], g1[R / 2];
+                lds_row<R>(ldsG, e.x & 0xFFFFu, g0);
+                for (int g = 0; g < ng; g++) {
+                    const uint4 c = e;
+                    e = E[(size_t)min(g + 1, ng - 1) * 64];               // prefetch (re-reads the last group at the end)
+                    lds_row<R>(ldsG, c.y & 0xFFFFu, g1);
+                    sweep_entry<R>(T, g0, (double)(c.x >> 16), (c.x >> 16) != 0, LOGTERM);
+                    lds_row<R>(ldsG, c.z & 0xFFFFu, g0);
+                    sweep_entry<R>(T, g1, (double)(c.y >> 16), (c.y >> 16) != 0, LOGTERM);
+                    lds_row<R>(ldsG, c.w & 0xFFFFu, g1);
+                    sweep_entry<R>(T, g0, (double)(c.z >> 16), (c.z >> 16) != 0, LOGTERM);
+                    lds_row<R>(ldsG, e.x & 0xFFFFu, g0);
+                    sweep_entry<R>(T, g1, (double)(c.w >> 16), (c.w >> 16) != 0, LOGTERM);
+                }
+            } else {
+                const uint4 *E = reinterpret_cast<const uint4 *>(S.widx + off) + lane;
+                const double2 *V = reinterpret_cast<const double2 *>(S.wval + off) + lane * 2;
+                double2 g0[R / 2], g1[R / 2];
+                for (int g = 0; g < ng; g++) {
+                    const uint4 c = E[(size_t)g * 64];
+                    const double2 v0 = V[(size_t)g * 128], v1 = V[(size_t)g * 128 + 1];
+                    lds_row<R>(ldsG, c.x, g0);
+                    lds_row<R>(ldsG, c.y, g1);
+                    sweep_entry<R>(T, g0, v0.x, v0.x != 0.0, LOGTERM);
+                    lds_row<R>(ldsG, c.z, g0);
+                    sweep_entry<R>(T, g1, v0.y, v0.y != 0.0, LOGTERM);
+                    lds_row<R>(ldsG, c.w, g1);
+                    sweep_entry<R>(T, g0, v1.x, v1.x != 0.0, LOGTERM);
+                    sweep_entry<R>(T, g1, v1.y, v1.y != 0.0, LOGTERM);
+                }
+            }
+
+            // partial statistics of this task and the lane's evidence contribution
+            double ev = 0.0;
+            {
+                double2 *P = reinterpret_cast<double2 *>(S.part + ((size_t)s * 64 + lane) * R);
+#pragma unroll
+                for (int kk = 0; kk < R / 2; kk++) P[kk] = make_double2(T.acc[2 * kk], T.acc[2 * kk + 1]);
+            }
+            if (M != kIdle) {
+                const double2 *L2 = reinterpret_cast<const double2 *>(S.llF + (size_t)M * R);
+#pragma unroll
+                for (int kk = 0; kk < R / 2; kk++) {
+                    const double2 l = L2[kk];
+                    ev = fma(T.acc[2 * kk], l.x, ev);
+                    ev = fma(T.acc[2 * kk + 1], l.y, ev);
+                }
+                ev -= T.lsum;
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) ev += __shfl_down(ev, d, 64);
+            if (lane == 0) S.epart[s] = ev;
+        }
+    }
 }
 
 template <int R, bool WIDE, int NT>
 __global__ __launch_bounds__(NT) void k_sweep(const SweepSide A, const SweepSide B)
 {
     extern __shared__ double2 ldsG[];
-    const bool second = (int)blockIdx.x >= A.n_tiles;
-    const SweepSide &S = second ? B : A;
-    const int tile = (int)blockIdx.x - (second ? A.n_tiles : 0);
-    const int blk = S.tile_block[tile];
-    const int64_t s0 = S.tile_slice0[tile], s1 = S.tile_slice0[tile + 1];
-    const int m0 = blk * S.block_width;
-    const int cw = min(S.block_width, S.n_minor - m0);
-    const bool logterm = S.logterm != 0;
+    sweep_side<R, WIDE, true, NT>(A, ldsG);      // lanes own genes: statistics sw + the sum x log(wth)
+    sweep_side<R, WIDE, false, NT>(B, ldsG);     // lanes own cells: statistics sh
+}
 
-    // stage the minor block of G: cw rows of R doubles, contiguous in HBM
-    {
-        const double2 *G2 = reinterpret_cast<const double2 *>(S.G + (size_t)m0 * R);
-        const int cnt = cw * (R / 2);
-        for (int t = threadIdx.x; t < cnt; t += NT) ldsG[t] = G2[t];
-    }
-    __syncthreads();
-
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int64_t s = s0 + wave; s < s1; s += NT / 64) {
-        const uint32_t M = S.slice_major[s * 64 + lane];
-        const int w = S.slice_width[s];
-        const int64_t off = S.slice_off[s];
-        SweepRegs<R> T;
-        if (M != kIdle) {
-            const double2 *F2 = reinterpret_cast<const double2 *>(S.F + (size_t)M * R);
-#pragma unroll
-            for (int kk = 0; kk < R / 2; kk++) { double2 v = F2[kk]; T.F[2 * kk] = v.x; T.F[2 * kk + 1] = v.y; }
-        } else {
-#pragma unroll
-            for (int k = 0; k < R; k++) T.F[k] = 1.0;   // idle lane: only sees padding slots
-        }
-#pragma unroll
-        for (int k = 0; k < R; k++) T.acc[k] = 0.0;
-        T.lsum = 0.0;
-
-        const int ng = w >> 2;
-        if (!WIDE) {
-            const uint4 *E = reinterpret_cast<const uint4 *>(S.packed + off) + lane;
-            uint4 e = ng > 0 ? E[0] : make_uint4(0, 0, 0, 0);
-            for (int g = 0; g < ng; g++) {
-                const uint4 c = e;
-                if (g + 1 < ng) e = E[(size_t)(g + 1) * 64];
-                sweep_entry<R>(T, ldsG, c.x & 0xFFFFu, (double)(c.x >> 16), (c.x >> 16) != 0, logterm);
-                sweep_entry<R>(T, ldsG, c.y & 0xFFFFu, (double)(c.y >> 16), (c.y >> 16) != 0, logterm);
-                sweep_entry<R>(T, ldsG, c.z & 0xFFFFu, (double)(c.z >> 16), (c.z >> 16) != 0, logterm);
-                sweep_entry<R>(T, ldsG, c.w & 0xFFFFu, (double)(c.w >> 16), (c.w >> 16) != 0, logterm);
-            }
-        } else {
-            const uint4 *E = reinterpret_cast<const uint4 *>(S.widx + off) + lane;
-            const double2 *V = reinterpret_cast<const double2 *>(S.wval + off) + lane * 2;
-            for (int g = 0; g < ng; g++) {
-                const uint4 c = E[(size_t)g * 64];
-                const double2 v0 = V[(size_t)g * 128], v1 = V[(size_t)g * 128 + 1];
-                sweep_entry<R>(T, ldsG, c.x, v0.x, v0.x != 0.0, logterm);
-                sweep_entry<R>(T, ldsG, c.y, v0.y, v0.y != 0.0, logterm);
-                sweep_entry<R>(T, ldsG, c.z, v1.x, v1.x != 0.0, logterm);
-                sweep_entry<R>(T, ldsG, c.w, v1.y, v1.y != 0.0, logterm);
-            }
-        }
-
-        // partial statistics of this (major, block) and the lane's evidence contribution
-        double ev = 0.0;
-        if (M != kIdle) {
-            double2 *P = reinterpret_cast<double2 *>(S.part + ((size_t)blk * S.n_major + M) * R);
-            const double2 *L2 = reinterpret_cast<const double2 *>(S.llF + (size_t)M * R);
-#pragma unroll
-            for (int kk = 0; kk < R / 2; kk++) {
-                P[kk] = make_double2(T.acc[2 * kk], T.acc[2 * kk + 1]);
-                const double2 l = L2[kk];
-                ev = fma(T.acc[2 * kk], l.x, ev);
-                ev = fma(T.acc[2 * kk + 1], l.y, ev);
-            }
-            ev -= T.lsum;
-        }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) ev += __shfl_down(ev, d, 64);
-        if (lane == 0) S.epart[s] = ev;
-    }
+// out[major][k] = sum over the major's tasks (fixed order) of part[task][k]
+__device__ __forceinline__ double task_sum(const double *__restrict__ part, const int32_t *__restrict__ inv_ptr,
+                                           const uint32_t *__restrict__ inv_task, int64_t M, int R, int k)
+{
+    double s = 0.0;
+    for (int q = inv_ptr[M]; q < inv_ptr[M + 1]; q++) s += part[(size_t)inv_task[q] * R + k];
+    return s;
 }
 
 // ------------------------------------------------------------------------------------
 // Posterior update of one factor (both sides share it).  One thread per (major, k).
-//   s   = sum_b acc[b][major][k]            partial statistics of the previous sweep
+//   s   = acc[major][k], or the sum of the major's task partials (inv_ptr != null)
 //   al  = a + l_old * s                     :38-39 / :48-49
 //   be  = a/b + other[k]                    :40-43 (rowSums of the incoming eh) / :50-53 (colSums of the NEW ew)
 //   e   = al/be ; d = al/be/be              :44,46 / :54,56
@@ -179,7 +257,8 @@ __global__ __launch_bounds__(NT) void k_sweep(const SweepSide A, const SweepSide
 // bp[block][R] = sum term, bp[block][R+1] = sum log l.
 // ------------------------------------------------------------------------------------
 template <int R>
-__global__ __launch_bounds__(256) void k_update(const double *__restrict__ acc, int nacc, int64_t nmaj, int r,
+__global__ __launch_bounds__(256) void k_update(const double *__restrict__ acc, const int32_t *__restrict__ inv_ptr,
+                                                const uint32_t *__restrict__ inv_task, int64_t nmaj, int r,
                                                 const double *__restrict__ other, double a, double b, double lga,
                                                 double fudge, double *__restrict__ l, double *__restrict__ ll,
                                                 double *__restrict__ e, double *__restrict__ d, double *__restrict__ bp)
@@ -193,8 +272,7 @@ __global__ __launch_bounds__(256) void k_update(const double *__restrict__ acc, 
     if (row < RB && M < nmaj) {
         const size_t o = (size_t)M * R + k;
         if (k < r) {
-            double s = 0.0;
-            for (int q = 0; q < nacc; q++) s += acc[(size_t)q * nmaj * R + o];
+            const double s = inv_ptr ? task_sum(acc, inv_ptr, inv_task, M, R, k) : acc[o];
             const double al = a + l[o] * s;
             const double be = a / b + other[k];
             ve = al / be;
@@ -293,15 +371,17 @@ __global__ __launch_bounds__(256) void k_reduce(const ReduceArgs a)
     }
 }
 
-// swsum[e] = sum_b part[b][e]  (e over n_major*R), blocks in index order.
-__global__ __launch_bounds__(256) void k_pack(const double *__restrict__ part, int nblk, int64_t count,
+// out[major][k] = sum of the major's task partials, fixed order (the gene-side statistics
+// in the form a cell-partitioned run all-reduces).
+__global__ __launch_bounds__(256) void k_pack(const double *__restrict__ part, const int32_t *__restrict__ inv_ptr,
+                                              const uint32_t *__restrict__ inv_task, int64_t nmaj, int R,
                                               double *__restrict__ out)
 {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= count) return;
-    double s = 0.0;
-    for (int b = 0; b < nblk; b++) s += part[(size_t)b * count + e];
-    out[e] = s;
+    if (e >= nmaj * R) return;
+    const int64_t M = e / R;
+    const int k = (int)(e - M * R);
+    out[e] = task_sum(part, inv_ptr, inv_task, M, R, k);
 }
 
 // Evidence and the four hyper statistics from the reduced scalars.

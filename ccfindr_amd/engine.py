@@ -188,7 +188,7 @@ class VBEngine:
     def layout_info(self):
         v = [ctypes.c_int64() for _ in range(6)]
         N.check(self._lib.vbnmf_engine_layout_info(self._h, *[ctypes.byref(x) for x in v]))
-        keys = ("nnz", "slots_gene_side", "slots_cell_side", "stream_bytes_per_step", "tiles_gene_side", "tiles_cell_side")
+        keys = ("nnz", "slots_gene_side", "slots_cell_side", "stream_bytes_per_step", "tasks_gene_side", "tasks_cell_side")
         return dict(zip(keys, (x.value for x in v)))
 
     def close(self):

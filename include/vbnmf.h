@@ -145,10 +145,10 @@ int vbnmf_engine_timing_enable(vbnmf_engine *e, int32_t on);
 int vbnmf_engine_timing_get(vbnmf_engine *e, double *sweep_ms, int64_t *sweep_launches);
 
 /* Layout facts for roofline accounting / tests (any pointer may be NULL):
- * padded entry slots and bytes the two sweeps stream per step, tile counts. */
+ * padded entry slots and bytes the two sweeps stream per step, task counts. */
 int vbnmf_engine_layout_info(const vbnmf_engine *e, int64_t *nnz, int64_t *slots_gene_side,
                              int64_t *slots_cell_side, int64_t *stream_bytes_per_step,
-                             int64_t *tiles_gene_side, int64_t *tiles_cell_side);
+                             int64_t *tasks_gene_side, int64_t *tasks_cell_side);
 
 /* ---------------------------------------------------------------------------------
  * Stateless form: the reference's call, one X in, one updated `wh` out
@@ -172,7 +172,7 @@ int vbnmf_update_csc(int64_t n, int64_t m, int32_t r, const int32_t *p, const in
 /* ---------------------------------------------------------------------------------
  * Host-only inspection of the tiled device layout (no GPU needed): builds the layout
  * for one side at padded rank r and hands out its arrays so tests can check, bit for
- * bit, that the tiles hold exactly X.  side 0 = gene side (lanes own genes, minor =
+ * bit, that the slices hold exactly X.  side 0 = gene side (lanes own genes, minor =
  * cells), 1 = cell side.  The returned pointers belong to the layout object.
  * --------------------------------------------------------------------------------- */
 typedef struct vbnmf_layout vbnmf_layout;
@@ -181,15 +181,21 @@ typedef struct {
     int64_t n_major, n_minor;      /* lanes own majors; minors are gathered from LDS */
     int32_t block_width;           /* minors per LDS block */
     int32_t n_blocks;              /* ceil(n_minor / block_width) */
-    int32_t chunk;                 /* majors per tile (multiple of 64) */
-    int64_t n_tiles, n_slices;     /* tile = (major chunk, minor block); slice = 64 lanes */
+    int32_t max_len;               /* longest task (entries per lane) */
+    int32_t n_wg;                  /* persistent workgroups the slice list is cut for */
+    int64_t n_tasks, n_slices;     /* task = run of one major's entries in one block; slice = 64 tasks */
     int64_t n_slots;               /* padded entry slots (all slices) */
-    const int32_t *tile_block;     /* [n_tiles] minor block of the tile */
-    const int64_t *tile_slice0;    /* [n_tiles+1] first slice of each tile */
-    const uint32_t *slice_major;   /* [n_slices*64] major id per lane, 0xFFFFFFFF = idle lane */
+    int64_t n_segs;                /* segment = run of slices of one block in one workgroup's range */
+    const uint32_t *task_major;    /* [n_slices*64] major of task slice*64+lane, 0xFFFFFFFF = idle lane */
     const int32_t *slice_width;    /* [n_slices] entries per lane (multiple of 4) */
     const int64_t *slice_off;      /* [n_slices] first slot of the slice; slot(t, lane) =
                                       off + (t/4)*256 + lane*4 + t%4 */
+    const int32_t *slice_block;    /* [n_slices] minor block */
+    const int32_t *seg_block;      /* [n_segs] */
+    const int32_t *seg_slice0;     /* [n_segs+1] */
+    const int32_t *wg_seg0;        /* [n_wg+1] */
+    const int32_t *inv_ptr;        /* [n_major+1] tasks of each major ... */
+    const uint32_t *inv_task;      /* [n_tasks]   ... in the order their partials are summed */
     const uint32_t *packed;        /* [n_slots] (count << 16) | local minor    (wide == 0) */
     const uint32_t *wide_idx;      /* [n_slots] local minor                    (wide == 1) */
     const double *wide_val;        /* [n_slots]                                (wide == 1) */

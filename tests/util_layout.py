@@ -14,14 +14,18 @@ def build_layout(M, side, r, cols=None):
     v = N.LayoutView()
     N.check(L.vbnmf_layout_build(M._h, cb, ce, side, r, ctypes.byref(h), ctypes.byref(v)))
     try:
-        out = {k: getattr(v, k) for k in ("side", "wide", "n_major", "n_minor", "block_width", "n_blocks", "chunk",
-                                          "n_tiles", "n_slices", "n_slots")}
-        arr = lambda p, cnt: np.ctypeslib.as_array(p, shape=(cnt,)).copy() if cnt else np.zeros(0)
-        out["tile_block"] = arr(v.tile_block, v.n_tiles)
-        out["tile_slice0"] = arr(v.tile_slice0, v.n_tiles + 1)
-        out["slice_major"] = arr(v.slice_major, v.n_slices * 64)
+        out = {k: getattr(v, k) for k in ("side", "wide", "n_major", "n_minor", "block_width", "n_blocks", "max_len",
+                                          "n_wg", "n_tasks", "n_slices", "n_slots", "n_segs")}
+        arr = lambda p, cnt: np.ctypeslib.as_array(p, shape=(cnt,)).copy() if cnt else np.zeros(0, dtype=np.int64)
+        out["task_major"] = arr(v.task_major, v.n_slices * 64)
         out["slice_width"] = arr(v.slice_width, v.n_slices)
         out["slice_off"] = arr(v.slice_off, v.n_slices)
+        out["slice_block"] = arr(v.slice_block, v.n_slices)
+        out["seg_block"] = arr(v.seg_block, v.n_segs)
+        out["seg_slice0"] = arr(v.seg_slice0, v.n_segs + 1)
+        out["wg_seg0"] = arr(v.wg_seg0, v.n_wg + 1)
+        out["inv_ptr"] = arr(v.inv_ptr, v.n_major + 1)
+        out["inv_task"] = arr(v.inv_task, v.n_tasks)
         if v.wide:
             out["wide_idx"] = arr(v.wide_idx, v.n_slots)
             out["wide_val"] = arr(v.wide_val, v.n_slots)
@@ -33,33 +37,60 @@ def build_layout(M, side, r, cols=None):
 
 
 def reconstruct(view):
-    """Dense [n_major, n_minor] matrix the layout encodes, plus the list of (major, block) pairs seen."""
+    """Dense [n_major, n_minor] matrix the layout encodes; checks the structural invariants on the way."""
     A = np.zeros((view["n_major"], view["n_minor"]))
-    seen = np.zeros((view["n_major"], view["n_blocks"]), dtype=np.int64)
     C = view["block_width"]
-    for t in range(view["n_tiles"]):
-        blk = view["tile_block"][t]
-        for s in range(view["tile_slice0"][t], view["tile_slice0"][t + 1]):
-            w, off = view["slice_width"][s], view["slice_off"][s]
-            assert w % 4 == 0 and off % 256 == 0
-            for lane in range(64):
-                M = view["slice_major"][s * 64 + lane]
-                tt = np.arange(w)
-                slots = off + (tt // 4) * 256 + lane * 4 + tt % 4
-                if view["wide"]:
-                    idx, val = view["wide_idx"][slots], view["wide_val"][slots]
-                else:
-                    e = view["packed"][slots]
-                    idx, val = e & 0xFFFF, (e >> 16).astype(np.float64)
-                if M == 0xFFFFFFFF:
-                    assert not val.any()
-                    continue
-                seen[M, blk] += 1
-                live = val != 0
-                assert (idx[~live] == 0).all()
-                cols = blk * C + idx[live]
-                assert (cols < min((blk + 1) * C, view["n_minor"])).all()
-                assert np.all(np.diff(cols) > 0)          # minors ascending within a lane
-                assert not live[np.argmin(live):].any() if not live.all() else True   # padding only at the tail
-                A[M, cols] += val[live]
-    return A, seen
+    ntask = 0
+    first_minor = {}
+    for s in range(view["n_slices"]):
+        blk = view["slice_block"][s]
+        w, off = view["slice_width"][s], view["slice_off"][s]
+        assert w % 4 == 0 and w >= 4 and w <= view["max_len"] and off % 256 == 0
+        lens = []
+        for lane in range(64):
+            tid = s * 64 + lane
+            M = view["task_major"][tid]
+            tt = np.arange(w)
+            slots = off + (tt // 4) * 256 + lane * 4 + tt % 4
+            if view["wide"]:
+                idx, val = view["wide_idx"][slots], view["wide_val"][slots]
+            else:
+                e = view["packed"][slots]
+                idx, val = e & 0xFFFF, (e >> 16).astype(np.float64)
+            if M == 0xFFFFFFFF:
+                assert not val.any() and not idx.any()
+                lens.append(0)
+                continue
+            ntask += 1
+            live = val != 0
+            n_live = int(live.sum())
+            assert n_live >= 1 and live[:n_live].all()        # entries first, padding only at the tail
+            assert (idx[~live] == 0).all()
+            cols = blk * C + idx[live]
+            assert (cols < min((blk + 1) * C, view["n_minor"])).all()
+            assert np.all(np.diff(cols) > 0)                   # minors ascending within a task
+            assert (A[M, cols] == 0).all()                     # no entry stored twice
+            A[M, cols] += val[live]
+            first_minor[tid] = int(cols[0])
+            lens.append(n_live)
+        assert lens == sorted(lens, reverse=True)              # longest task first: width = first lane
+        assert (w - lens[0]) < 4
+    assert ntask == view["n_tasks"]
+    # inverse index: every task exactly once, under its own major, in ascending minor order
+    seen = np.zeros(view["n_slices"] * 64, dtype=np.int64)
+    for M in range(view["n_major"]):
+        ids = view["inv_task"][view["inv_ptr"][M]:view["inv_ptr"][M + 1]]
+        seen[ids] += 1
+        assert (view["task_major"][ids] == M).all()
+        fm = [first_minor[int(t)] for t in ids]
+        assert fm == sorted(fm)
+    assert (seen[view["task_major"] != 0xFFFFFFFF] == 1).all() and seen.sum() == view["n_tasks"]
+    # persistent-workgroup ranges: segments tile the slice list in order, one block per segment
+    assert view["wg_seg0"][0] == 0 and view["wg_seg0"][-1] == view["n_segs"]
+    assert np.all(np.diff(view["wg_seg0"]) >= 0)
+    assert view["seg_slice0"][0] == 0 and view["seg_slice0"][-1] == view["n_slices"]
+    assert np.all(np.diff(view["seg_slice0"]) > 0)
+    for g in range(view["n_segs"]):
+        sl = view["slice_block"][view["seg_slice0"][g]:view["seg_slice0"][g + 1]]
+        assert (sl == view["seg_block"][g]).all()
+    return A
