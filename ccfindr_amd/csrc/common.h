@@ -45,6 +45,7 @@ double sum_lgamma_x1(const Matrix &X, int64_t cb, int64_t ce);
 // LDS once per segment).
 constexpr int kLanes = 64;          // one slice = one wavefront
 constexpr int kUnroll = 4;          // entries per lane per 16-byte load
+constexpr int kWidthQuantum = 8;    // slice widths are multiples of this (two loads per loop trip)
 constexpr uint32_t kIdleLane = 0xFFFFFFFFu;
 
 struct Layout {
@@ -76,7 +77,7 @@ struct LayoutParams {
 // Padded rank used on the device (even, so a factor row is a whole number of 16-byte LDS reads).
 inline int padded_rank(int r) { return (r + 1) & ~1; }
 // Threads per workgroup of the sweep kernel at padded rank R.
-constexpr int sweep_threads(int R) { return R <= 4 ? 1024 : 512; }
+constexpr int sweep_threads(int R) { return R <= 4 ? 1024 : (R <= 10 ? 768 : 512); }
 // Default block width / task length for a side at padded rank R; n_wg <= 0 picks the default (256).
 LayoutParams default_layout_params(int64_t n_major, int64_t n_minor, int R, int n_wg = 0);
 

@@ -261,8 +261,8 @@ LayoutParams default_layout_params(int64_t n_major, int64_t n_minor, int R, int 
     if (c > cmax) c = cmax;
     lp.block_width = (int32_t)c;
     int ml = env_int("VBNMF_MAX_LEN", 256);
-    if (ml < kUnroll) ml = kUnroll;
-    lp.max_len = (ml + kUnroll - 1) / kUnroll * kUnroll;
+    if (ml < kWidthQuantum) ml = kWidthQuantum;
+    lp.max_len = (ml + kWidthQuantum - 1) / kWidthQuantum * kWidthQuantum;
     if (n_wg <= 0) n_wg = env_int("VBNMF_NWG", 256);
     if (n_wg < 1) n_wg = 1;
     lp.n_wg = n_wg;
@@ -272,7 +272,7 @@ LayoutParams default_layout_params(int64_t n_major, int64_t n_minor, int R, int 
 int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const LayoutParams &lp, Layout &L)
 {
     if (cb < 0 || ce > X.m || cb >= ce) return fail(VBNMF_ERR_BAD_ARG, "column range [%lld, %lld) is outside the matrix", (long long)cb, (long long)ce);
-    if (lp.block_width <= 0 || lp.block_width > 65536 || lp.max_len <= 0 || lp.max_len % kUnroll || lp.n_wg <= 0)
+    if (lp.block_width <= 0 || lp.block_width > 65536 || lp.max_len <= 0 || lp.max_len % kWidthQuantum || lp.n_wg <= 0)
         return fail(VBNMF_ERR_BAD_ARG, "bad layout parameters");
 
     // major-compressed view of X[:, cb:ce)
@@ -357,7 +357,7 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
         }
         for (int64_t s = bslice0[blk]; s < bslice0[blk + 1]; s++) {
             int32_t w = task_len[(size_t)s * kLanes];            // sorted: first lane is the longest
-            L.slice_width[s] = (w + kUnroll - 1) / kUnroll * kUnroll;
+            L.slice_width[s] = (w + kWidthQuantum - 1) / kWidthQuantum * kWidthQuantum;
             L.slice_block[s] = blk;
         }
     }

@@ -55,7 +55,8 @@ struct SweepSide {
     int32_t n_wg;
 };
 
-// ln(x) for finite x > 0 (also subnormal); x == 0 gives -inf, NaN propagates.  The
+// ln(x) for finite x > 0 (also subnormal); NaN propagates; x == 0 is not special-cased (the
+// sweep has already turned such an entry into NaN through x / wth).  The
 // argument reduction and degree-7 minimax polynomial in s^2, s = f/(2+f), are the
 // classical ones (x = 2^k (1+f), sqrt(1/2) <= 1+f < sqrt(2)); < 1 ulp, checked against
 // mpmath in tests.  Branch-free so the sweep's inner loop stays one basic block
@@ -81,8 +82,7 @@ __device__ __forceinline__ double dev_log(double x)
     const double hfsq = 0.5 * f * f;
     const double dk = (double)k;
     const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
-    double res = dk * ln2_hi - ((hfsq - (s * (hfsq + Rp) + dk * ln2_lo)) - f);
-    return x == 0.0 ? -__builtin_inf() : res;
+    return dk * ln2_hi - ((hfsq - (s * (hfsq + Rp) + dk * ln2_lo)) - f);
 }
 
 // x / w for finite w of ordinary magnitude: reciprocal seed, two Newton steps, one residual
@@ -103,18 +103,45 @@ struct SweepRegs {
     double lsum;
 };
 
+// One row (R doubles) of the staged factor block, by byte offset into the LDS image.
 template <int R>
-__device__ __forceinline__ void lds_row(const double2 *__restrict__ ldsG, uint32_t idx, double2 (&gv)[R / 2])
+__device__ __forceinline__ void lds_row(const double2 *__restrict__ ldsG, uint32_t byte_off, double2 (&gv)[R / 2])
 {
-    const double2 *g = ldsG + idx * (R / 2);
+    const double2 *g = reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(ldsG) + byte_off);
 #pragma unroll
     for (int kk = 0; kk < R / 2; kk++) gv[kk] = g[kk];
 }
 
-// One stored entry: wth = F . g ; q = x / wth ; acc += q g ; lsum += x log(wth).
-// Padding slots have x = 0 and are computed on wth := 1 so they add exact zeros.
+// A 4-entry group of the packed stream, unpacked: LDS byte offset of the minor's row and the count.
+// The loop carries these (not the raw words) from one trip to the next: the unpacking is work
+// the trip needs anyway, and a loop-carried value that is not a bare load result cannot be
+// folded back into a load at the top of the consuming trip (which would undo the prefetch).
+struct Group4 {
+    uint32_t o0, o1, o2, o3;
+    uint32_t c0, c1, c2, c3;
+};
+// Pins the unpacked group in VGPRs at this point of the trip: an empty asm the compiler can
+// neither sink into the next trip nor look through.
+__device__ __forceinline__ void pin(Group4 &g)
+{
+    asm volatile("" : "+v"(g.o0), "+v"(g.o1), "+v"(g.o2), "+v"(g.o3), "+v"(g.c0), "+v"(g.c1), "+v"(g.c2), "+v"(g.c3));
+}
 template <int R>
-__device__ __forceinline__ void sweep_entry(SweepRegs<R> &S, const double2 (&gv)[R / 2], double x, bool live, bool logterm)
+__device__ __forceinline__ Group4 unpack4(const uint4 e)
+{
+    Group4 g;
+    g.o0 = (e.x & 0xFFFFu) * (R * 8); g.o1 = (e.y & 0xFFFFu) * (R * 8);
+    g.o2 = (e.z & 0xFFFFu) * (R * 8); g.o3 = (e.w & 0xFFFFu) * (R * 8);
+    g.c0 = e.x >> 16; g.c1 = e.y >> 16; g.c2 = e.z >> 16; g.c3 = e.w >> 16;
+    return g;
+}
+
+// One stored entry: wth = F . g ; q = x / wth ; acc += q g ; lsum += x log(wth).
+// Padding slots have x = 0 and minor 0 of the block: they add exact zeros as long as wth
+// there is finite and non-zero.  It can only fail to be when a whole factor row is 0 or
+// non-finite, and then the reference's dense X/wth (src/vbnmf_update.cpp:34) is NaN as well.
+template <int R>
+__device__ __forceinline__ void sweep_entry(SweepRegs<R> &S, const double2 (&gv)[R / 2], double x, bool logterm)
 {
     double wth = 0.0;
 #pragma unroll
@@ -122,7 +149,6 @@ __device__ __forceinline__ void sweep_entry(SweepRegs<R> &S, const double2 (&gv)
         wth = fma(S.F[2 * kk], gv[kk].x, wth);
         wth = fma(S.F[2 * kk + 1], gv[kk].y, wth);
     }
-    wth = live ? wth : 1.0;
     const double q = dev_div(x, wth);
 #pragma unroll
     for (int kk = 0; kk < R / 2; kk++) {
@@ -169,38 +195,52 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
             for (int k = 0; k < R; k++) T.acc[k] = 0.0;
             T.lsum = 0.0;
 
+            // Slice widths are multiples of 8: two 4-entry groups per trip, the loads of the
+            // next trip issued before this trip's arithmetic, LDS rows fetched one entry ahead.
+            const int np = ng >> 1;
+            double2 g0[R / 2], g1[R / 2];
             if (!WIDE) {
                 const uint4 *E = reinterpret_cast<const uint4 *>(S.packed + off) + lane;
-                uint4 e = E[0];                                           // every slice has ng >= 1
-                double2 g0[R / 2], g1[R / 2];
-                lds_row<R>(ldsG, e.x & 0xFFFFu, g0);
-                for (int g = 0; g < ng; g++) {
-                    const uint4 c = e;
-                    e = E[(size_t)min(g + 1, ng - 1) * 64];               // prefetch (re-reads the last group at the end)
-                    lds_row<R>(ldsG, c.y & 0xFFFFu, g1);
-                    sweep_entry<R>(T, g0, (double)(c.x >> 16), (c.x >> 16) != 0, LOGTERM);
-                    lds_row<R>(ldsG, c.z & 0xFFFFu, g0);
-                    sweep_entry<R>(T, g1, (double)(c.y >> 16), (c.y >> 16) != 0, LOGTERM);
-                    lds_row<R>(ldsG, c.w & 0xFFFFu, g1);
-                    sweep_entry<R>(T, g0, (double)(c.z >> 16), (c.z >> 16) != 0, LOGTERM);
-                    lds_row<R>(ldsG, e.x & 0xFFFFu, g0);
-                    sweep_entry<R>(T, g1, (double)(c.w >> 16), (c.w >> 16) != 0, LOGTERM);
+                Group4 a = unpack4<R>(E[0]), b = unpack4<R>(E[64]);
+                lds_row<R>(ldsG, a.o0, g0);
+                for (int p = 0; p < np; p++) {
+                    const int pn = min(p + 1, np - 1);                    // last trip re-reads itself
+                    const uint4 ec = E[(size_t)pn * 128], ed = E[(size_t)pn * 128 + 64];
+                    lds_row<R>(ldsG, a.o1, g1);
+                    sweep_entry<R>(T, g0, (double)a.c0, LOGTERM);
+                    lds_row<R>(ldsG, a.o2, g0);
+                    sweep_entry<R>(T, g1, (double)a.c1, LOGTERM);
+                    lds_row<R>(ldsG, a.o3, g1);
+                    sweep_entry<R>(T, g0, (double)a.c2, LOGTERM);
+                    lds_row<R>(ldsG, b.o0, g0);
+                    sweep_entry<R>(T, g1, (double)a.c3, LOGTERM);
+                    lds_row<R>(ldsG, b.o1, g1);
+                    sweep_entry<R>(T, g0, (double)b.c0, LOGTERM);
+                    lds_row<R>(ldsG, b.o2, g0);
+                    sweep_entry<R>(T, g1, (double)b.c1, LOGTERM);
+                    lds_row<R>(ldsG, b.o3, g1);
+                    sweep_entry<R>(T, g0, (double)b.c2, LOGTERM);
+                    a = unpack4<R>(ec);
+                    pin(a);
+                    lds_row<R>(ldsG, a.o0, g0);
+                    sweep_entry<R>(T, g1, (double)b.c3, LOGTERM);
+                    b = unpack4<R>(ed);
+                    pin(b);
                 }
             } else {
                 const uint4 *E = reinterpret_cast<const uint4 *>(S.widx + off) + lane;
                 const double2 *V = reinterpret_cast<const double2 *>(S.wval + off) + lane * 2;
-                double2 g0[R / 2], g1[R / 2];
                 for (int g = 0; g < ng; g++) {
                     const uint4 c = E[(size_t)g * 64];
                     const double2 v0 = V[(size_t)g * 128], v1 = V[(size_t)g * 128 + 1];
-                    lds_row<R>(ldsG, c.x, g0);
-                    lds_row<R>(ldsG, c.y, g1);
-                    sweep_entry<R>(T, g0, v0.x, v0.x != 0.0, LOGTERM);
-                    lds_row<R>(ldsG, c.z, g0);
-                    sweep_entry<R>(T, g1, v0.y, v0.y != 0.0, LOGTERM);
-                    lds_row<R>(ldsG, c.w, g1);
-                    sweep_entry<R>(T, g0, v1.x, v1.x != 0.0, LOGTERM);
-                    sweep_entry<R>(T, g1, v1.y, v1.y != 0.0, LOGTERM);
+                    lds_row<R>(ldsG, c.x * (R * 8), g0);
+                    lds_row<R>(ldsG, c.y * (R * 8), g1);
+                    sweep_entry<R>(T, g0, v0.x, LOGTERM);
+                    lds_row<R>(ldsG, c.z * (R * 8), g0);
+                    sweep_entry<R>(T, g1, v0.y, LOGTERM);
+                    lds_row<R>(ldsG, c.w * (R * 8), g1);
+                    sweep_entry<R>(T, g0, v1.x, LOGTERM);
+                    sweep_entry<R>(T, g1, v1.y, LOGTERM);
                 }
             }
 

@@ -45,7 +45,7 @@ def reconstruct(view):
     for s in range(view["n_slices"]):
         blk = view["slice_block"][s]
         w, off = view["slice_width"][s], view["slice_off"][s]
-        assert w % 4 == 0 and w >= 4 and w <= view["max_len"] and off % 256 == 0
+        assert w % 8 == 0 and w >= 8 and w <= view["max_len"] and off % 256 == 0
         lens = []
         for lane in range(64):
             tid = s * 64 + lane
@@ -74,7 +74,7 @@ def reconstruct(view):
             first_minor[tid] = int(cols[0])
             lens.append(n_live)
         assert lens == sorted(lens, reverse=True)              # longest task first: width = first lane
-        assert (w - lens[0]) < 4
+        assert (w - lens[0]) < 8
     assert ntask == view["n_tasks"]
     # inverse index: every task exactly once, under its own major, in ascending minor order
     seen = np.zeros(view["n_slices"] * 64, dtype=np.int64)
