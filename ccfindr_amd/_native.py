@@ -80,6 +80,8 @@ SIGNATURES = {
                                         c_double_p, c_double_p, c_double_p] + [_D] * 5 + [c_double_p] * 7),
     "vbnmf_layout_build": (ctypes.c_int, [_VP, _I64, _I64, _I32, _I32, _VPP, ctypes.POINTER(LayoutView)]),
     "vbnmf_layout_destroy": (None, [_VP]),
+    "vbnmf_test_special_host": (ctypes.c_int, [_I32, _I64, c_double_p, c_double_p]),
+    "vbnmf_test_special_device": (ctypes.c_int, [_I32, _I64, c_double_p, c_double_p]),
 }
 
 _lib = None

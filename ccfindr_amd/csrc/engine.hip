@@ -1,11 +1,13 @@
 // engine.hip -- the device-resident VB-NMF engine behind the C ABI of include/vbnmf.h.
 //
-// One step (reference src/vbnmf_update.cpp:33-90) is seven launches on one HIP stream:
-//   k_update(W)  k_reduce(W)  k_update(H)  k_sweep(both sides)  k_pack  k_reduce(H, evidence)  k_final
+// One step (reference src/vbnmf_update.cpp:33-90) is four launches on one HIP stream:
+//   k_update(W)  k_update(H)  k_sweep(both sides)  k_final
 // The sweep at the end of step t produces the sufficient statistics that step t+1 starts
 // from AND the data term of step t's evidence (see kernels.h), so X is streamed once per
-// step and side.  The packed reduce buffer [swsum | rowSum(eh) | scalars] is what a
-// cell-partitioned run all-reduces between step_local and step_finish.
+// step and side.  k_final leaves lkh and the hyper statistics in pinned host memory and
+// raises a sequence flag the host polls (no memcpy, no stream synchronise on the hot path).
+// A cell-partitioned engine adds k_pack + k_tail, which fill the reduce buffer
+// [swsum | rowSum(eh) | scalars] that the caller all-reduces between step_local and step_finish.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -72,13 +74,13 @@ struct vbnmf_engine {
     double *lw = nullptr, *llw = nullptr, *ew = nullptr, *dw = nullptr;
     double *lh = nullptr, *llh = nullptr, *eh = nullptr, *dh = nullptr;
     double *epart = nullptr;          // [A.n_slices + B.n_slices]
-    double *bpW = nullptr, *bpH = nullptr;
-    int64_t nbW = 0, nbH = 0;
-    double *outW = nullptr;           // [R+2]
-    double *red = nullptr;            // [n*R | R+4]
+    double *bpW = nullptr, *bpH = nullptr;   // [kUpdateBlocks][R+2] block partials of the two updates
+    double *red = nullptr;            // [n*R | R+4]  (partitioned engines only use the first part)
     int64_t red_count = 0;
     double *d_out = nullptr;          // [8]
-    double *h_out = nullptr;          // pinned [8]
+    double *h_out = nullptr;          // pinned, device-visible [8]; [7] = sequence flag
+    double *h_out_dev = nullptr;      // device address of h_out
+    double seq = 0.0;
     size_t lds_bytes = 0;
     bool has_state = false, stats_ready = false, step_pending = false, prime_pending = false;
     bool timing = false;
@@ -184,17 +186,20 @@ int launch_sweep(vbnmf_engine *e)
 int launch_update(vbnmf_engine *e, bool gene_side, double a, double b, double fudge)
 {
     const double lga = -std::lgamma(a) + a * std::log(a / b);     // reference :82 / :87
-    const double *acc = gene_side ? e->red : e->B.part;
-    const int32_t *inv_ptr = gene_side ? nullptr : e->B.inv_ptr;
-    const uint32_t *inv_task = gene_side ? nullptr : e->B.inv_task;
+    const bool dense = gene_side && e->partitioned;               // statistics already summed into `red`
+    const DeviceSide &S = gene_side ? e->A : e->B;
+    const double *acc = dense ? e->red : S.part;
+    const int32_t *inv_ptr = dense ? nullptr : S.inv_ptr;
+    const uint32_t *inv_task = dense ? nullptr : S.inv_task;
     const int64_t nmaj = gene_side ? e->n : e->m;
-    const double *other = gene_side ? e->red + (size_t)e->n * e->R : e->outW;
+    const double *other = dense ? e->red + (size_t)e->n * e->R : nullptr;
+    const double *other_bp = dense ? nullptr : (gene_side ? e->bpH : e->bpW);
+    const int other_nb = dense ? 0 : kUpdateBlocks;
     double *l = gene_side ? e->lw : e->lh, *ll = gene_side ? e->llw : e->llh;
     double *ev = gene_side ? e->ew : e->eh, *d = gene_side ? e->dw : e->dh;
     double *bp = gene_side ? e->bpW : e->bpH;
-    const unsigned grid = (unsigned)(gene_side ? e->nbW : e->nbH);
     switch (e->R) {
-#define X(RR) case RR: hipLaunchKernelGGL((k_update<RR>), dim3(grid), dim3(256), 0, e->stream, acc, inv_ptr, inv_task, nmaj, e->r, other, a, b, lga, fudge, l, ll, ev, d, bp); break;
+#define X(RR) case RR: hipLaunchKernelGGL((k_update<RR>), dim3(kUpdateBlocks), dim3(kUpdateThreads), 0, e->stream, acc, inv_ptr, inv_task, nmaj, e->r, other, other_bp, other_nb, a, b, lga, fudge, l, ll, ev, d, bp); break;
         VBNMF_FOR_EACH_R(X)
 #undef X
         default: return fail(VBNMF_ERR_BAD_ARG, "unsupported padded rank %d", e->R);
@@ -210,9 +215,8 @@ int launch_prime(vbnmf_engine *e, bool gene_side)
     double *ll = gene_side ? e->llw : e->llh;
     const double *ev = gene_side ? nullptr : e->eh;
     double *bp = gene_side ? e->bpW : e->bpH;
-    const unsigned grid = (unsigned)(gene_side ? e->nbW : e->nbH);
     switch (e->R) {
-#define X(RR) case RR: hipLaunchKernelGGL((k_prime<RR>), dim3(grid), dim3(256), 0, e->stream, nmaj, e->r, l, ll, ev, bp); break;
+#define X(RR) case RR: hipLaunchKernelGGL((k_prime<RR>), dim3(kUpdateBlocks), dim3(kUpdateThreads), 0, e->stream, nmaj, e->r, l, ll, ev, bp); break;
         VBNMF_FOR_EACH_R(X)
 #undef X
         default: return fail(VBNMF_ERR_BAD_ARG, "unsupported padded rank %d", e->R);
@@ -223,9 +227,11 @@ int launch_prime(vbnmf_engine *e, bool gene_side)
 
 int launch_final(vbnmf_engine *e)
 {
-    const double *tail = e->red + (size_t)e->n * e->R;
+    const double *tail = e->partitioned ? e->red + (size_t)e->n * e->R : nullptr;
+    const int64_t nep = e->A.n_slices + e->B.n_slices;
+    e->seq += 1.0;
     switch (e->R) {
-#define X(RR) case RR: hipLaunchKernelGGL((k_final<RR>), dim3(1), dim3(64), 0, e->stream, e->outW, tail, e->r, (double)e->n, (double)e->m_global, e->d_out); break;
+#define X(RR) case RR: hipLaunchKernelGGL((k_final<RR>), dim3(1), dim3(1024), 0, e->stream, e->bpW, kUpdateBlocks, tail, e->bpH, kUpdateBlocks, e->epart, nep, e->lgx, e->r, (double)e->n, (double)e->m_global, e->seq, e->d_out, e->h_out_dev); break;
         VBNMF_FOR_EACH_R(X)
 #undef X
         default: return fail(VBNMF_ERR_BAD_ARG, "unsupported padded rank %d", e->R);
@@ -234,29 +240,34 @@ int launch_final(vbnmf_engine *e)
     return VBNMF_OK;
 }
 
-// reduce the gene-side block partials into outW = [colSum(ew) | sum W-terms | sum log lw]
-int launch_reduce_w(vbnmf_engine *e)
-{
-    ReduceArgs a{};
-    a.src = e->bpW; a.count = e->nbW; a.stride = e->R + 2; a.ncols = e->R + 2; a.dst = e->outW;
-    hipLaunchKernelGGL(k_reduce, dim3(a.ncols), dim3(256), 0, e->stream, a);
-    HIPCHECK(hipGetLastError());
-    return VBNMF_OK;
-}
-
-// sweep output -> reduce buffer: swsum, then tail = [rowSum(eh) | sum H-terms | sum log lh | data term | lgx]
+// partitioned engines: sweep output -> reduce buffer = [swsum | rowSum(eh) | sum H-terms | sum log lh | data term | lgx]
 int launch_pack(vbnmf_engine *e)
 {
     const int64_t cnt = e->n * e->R;
     hipLaunchKernelGGL(k_pack, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, e->stream, e->A.part, e->A.inv_ptr, e->A.inv_task, e->n, e->R, e->red);
     HIPCHECK(hipGetLastError());
-    double *tail = e->red + cnt;
-    ReduceArgs a{};
-    a.src = e->bpH; a.count = e->nbH; a.stride = e->R + 2; a.ncols = e->R + 2; a.dst = tail;
-    a.vsrc = e->epart; a.vcount = e->A.n_slices + e->B.n_slices; a.vdst = tail + e->R + 2;
-    a.cdst = tail + e->R + 3; a.cval = e->lgx;
-    hipLaunchKernelGGL(k_reduce, dim3(a.ncols + 1), dim3(256), 0, e->stream, a);
+    hipLaunchKernelGGL(k_tail, dim3(1), dim3(1024), 0, e->stream, e->bpH, kUpdateBlocks, e->R, e->epart,
+                       (int64_t)(e->A.n_slices + e->B.n_slices), e->lgx, e->red + cnt);
     HIPCHECK(hipGetLastError());
+    return VBNMF_OK;
+}
+
+// Wait for k_final's sequence flag in pinned memory; falls back to the stream if it takes long.
+int wait_result(vbnmf_engine *e)
+{
+    volatile double *flag = e->h_out + 7;
+    for (long spins = 0; *flag != e->seq; spins++) {
+        if (spins > 0 && (spins & 0xFFFF) == 0) {
+            hipError_t q = hipStreamQuery(e->stream);
+            if (q == hipSuccess) {
+                if (*flag == e->seq) break;
+                HIPCHECK(hipStreamSynchronize(e->stream));
+                if (*flag != e->seq) return fail(VBNMF_ERR_HIP, "the step finished but its result flag was never raised");
+                break;
+            }
+            if (q != hipErrorNotReady) return fail(VBNMF_ERR_HIP, "the step failed on the device: %s", hipGetErrorString(q));
+        }
+    }
     return VBNMF_OK;
 }
 
@@ -264,6 +275,7 @@ int harvest_timing(vbnmf_engine *e)
 {
     if (e->timing && e->ev_recorded) {
         float ms = 0.f;
+        HIPCHECK(hipEventSynchronize(e->ev1));
         HIPCHECK(hipEventElapsedTime(&ms, e->ev0, e->ev1));
         e->sweep_ms += ms;
         e->sweep_launches++;
@@ -314,7 +326,7 @@ void vbnmf_engine_destroy(vbnmf_engine *e)
     free_side(e->A); free_side(e->B);
     (void)hipFree(e->lw); (void)hipFree(e->llw); (void)hipFree(e->ew); (void)hipFree(e->dw);
     (void)hipFree(e->lh); (void)hipFree(e->llh); (void)hipFree(e->eh); (void)hipFree(e->dh);
-    (void)hipFree(e->epart); (void)hipFree(e->bpW); (void)hipFree(e->bpH); (void)hipFree(e->outW);
+    (void)hipFree(e->epart); (void)hipFree(e->bpW); (void)hipFree(e->bpH);
     (void)hipFree(e->red); (void)hipFree(e->d_out);
     if (e->h_out) (void)hipHostFree(e->h_out);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
@@ -371,25 +383,25 @@ int vbnmf_engine_create_part(const vbnmf_matrix *X, int64_t cb, int64_t ce, int6
     e->lds_bytes = (size_t)std::max(e->A.block_width, e->B.block_width) * e->R * sizeof(double);
 
     const size_t nR = (size_t)e->n * e->R, mR = (size_t)e->m * e->R;
-    const int RB = 256 / e->R;
-    e->nbW = (e->n + RB - 1) / RB;
-    e->nbH = (e->m + RB - 1) / RB;
+    const size_t bpn = (size_t)kUpdateBlocks * (e->R + 2);
     e->red_count = (int64_t)nR + e->R + 4;
     if ((rc = dev_alloc(&e->lw, nR)) || (rc = dev_alloc(&e->llw, nR)) || (rc = dev_alloc(&e->ew, nR)) || (rc = dev_alloc(&e->dw, nR)) ||
         (rc = dev_alloc(&e->lh, mR)) || (rc = dev_alloc(&e->llh, mR)) || (rc = dev_alloc(&e->eh, mR)) || (rc = dev_alloc(&e->dh, mR)) ||
         (rc = dev_alloc(&e->epart, (size_t)(e->A.n_slices + e->B.n_slices))) ||
-        (rc = dev_alloc(&e->bpW, (size_t)e->nbW * (e->R + 2))) || (rc = dev_alloc(&e->bpH, (size_t)e->nbH * (e->R + 2))) ||
-        (rc = dev_alloc(&e->outW, (size_t)e->R + 2)) || (rc = dev_alloc(&e->red, (size_t)e->red_count)) ||
-        (rc = dev_alloc(&e->d_out, 8)))
+        (rc = dev_alloc(&e->bpW, bpn)) || (rc = dev_alloc(&e->bpH, bpn)) ||
+        (rc = dev_alloc(&e->red, (size_t)e->red_count)) || (rc = dev_alloc(&e->d_out, 8)))
         return bail(rc);
     hipError_t he;
-    if ((he = hipHostMalloc((void **)&e->h_out, 8 * sizeof(double))) != hipSuccess ||
+    if ((he = hipHostMalloc((void **)&e->h_out, 8 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess ||
+        (he = hipHostGetDevicePointer((void **)&e->h_out_dev, e->h_out, 0)) != hipSuccess ||
         (he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)) != hipSuccess ||
         (he = hipEventCreate(&e->ev0)) != hipSuccess || (he = hipEventCreate(&e->ev1)) != hipSuccess)
         return bail(fail(VBNMF_ERR_HIP, "engine setup failed: %s", hipGetErrorString(he)));
     e->own_stream = true;
+    std::memset(e->h_out, 0, 8 * sizeof(double));
     if ((he = hipMemset(e->ew, 0, nR * sizeof(double))) != hipSuccess || (he = hipMemset(e->dw, 0, nR * sizeof(double))) != hipSuccess ||
-        (he = hipMemset(e->dh, 0, mR * sizeof(double))) != hipSuccess || (he = hipMemset(e->outW, 0, (e->R + 2) * sizeof(double))) != hipSuccess)
+        (he = hipMemset(e->dh, 0, mR * sizeof(double))) != hipSuccess || (he = hipMemset(e->bpW, 0, bpn * sizeof(double))) != hipSuccess ||
+        (he = hipMemset(e->bpH, 0, bpn * sizeof(double))) != hipSuccess || (he = hipMemset(e->red, 0, (size_t)e->red_count * sizeof(double))) != hipSuccess)
         return bail(fail(VBNMF_ERR_HIP, "hipMemset failed: %s", hipGetErrorString(he)));
     *out = e;
     return VBNMF_OK;
@@ -473,7 +485,7 @@ int vbnmf_engine_set_state(vbnmf_engine *e, const double *lw, const double *lh, 
     if (int rc = launch_prime(e, true)) return rc;
     if (int rc = launch_prime(e, false)) return rc;
     if (int rc = launch_sweep(e)) return rc;
-    if (int rc = launch_pack(e)) return rc;
+    if (e->partitioned) { if (int rc = launch_pack(e)) return rc; }
     e->prime_pending = true;
     if (!e->partitioned) return vbnmf_engine_state_finish(e);
     return VBNMF_OK;
@@ -499,10 +511,9 @@ int vbnmf_engine_step_local(vbnmf_engine *e, double aw, double bw, double ah, do
     if (e->step_pending) return fail(VBNMF_ERR_STATE, "step_local called twice without step_finish");
     if (int rc = use_device(e)) return rc;
     if (int rc = launch_update(e, true, aw, bw, fudge)) return rc;
-    if (int rc = launch_reduce_w(e)) return rc;
     if (int rc = launch_update(e, false, ah, bh, fudge)) return rc;
     if (int rc = launch_sweep(e)) return rc;
-    if (int rc = launch_pack(e)) return rc;
+    if (e->partitioned) { if (int rc = launch_pack(e)) return rc; }
     e->step_pending = true;
     return VBNMF_OK;
 }
@@ -521,8 +532,7 @@ int vbnmf_engine_step_finish(vbnmf_engine *e, double *lkh, double *stats)
     if (!e->step_pending) return fail(VBNMF_ERR_STATE, "step_finish without step_local");
     if (int rc = use_device(e)) return rc;
     if (int rc = launch_final(e)) return rc;
-    HIPCHECK(hipMemcpyAsync(e->h_out, e->d_out, 5 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-    HIPCHECK(hipStreamSynchronize(e->stream));
+    if (int rc = wait_result(e)) return rc;
     e->step_pending = false;
     if (int rc = harvest_timing(e)) return rc;
     if (lkh) *lkh = e->h_out[0];
@@ -589,6 +599,42 @@ int vbnmf_engine_layout_info(const vbnmf_engine *e, int64_t *nnz, int64_t *slots
     if (tiles_gene) *tiles_gene = e->A.n_tasks;
     if (tiles_cell) *tiles_cell = e->B.n_tasks;
     return VBNMF_OK;
+}
+
+// ---------------------------------------------------------------- test hooks
+int vbnmf_test_special_host(int32_t kind, int64_t n, const double *x, double *y)
+{
+    if (!x || !y || n < 0) return fail(VBNMF_ERR_BAD_ARG, "NULL argument");
+    for (int64_t i = 0; i < n; i++) {
+        double psi, lg;
+        switch (kind) {
+            case 0: y[i] = dev_log(x[i]); break;
+            case 1: dev_psi_lgamma(x[i], &psi, &lg); y[i] = psi; break;
+            case 2: dev_psi_lgamma(x[i], &psi, &lg); y[i] = lg; break;
+            default: y[i] = dev_div(1.0, x[i]); break;
+        }
+    }
+    return VBNMF_OK;
+}
+
+int vbnmf_test_special_device(int32_t kind, int64_t n, const double *x, double *y)
+{
+    if (!x || !y || n < 0) return fail(VBNMF_ERR_BAD_ARG, "NULL argument");
+    if (int rc = check_device(0)) return rc;
+    HIPCHECK(hipSetDevice(0));
+    double *dx = nullptr, *dy = nullptr;
+    if (int rc = dev_alloc(&dx, (size_t)n)) return rc;
+    if (int rc = dev_alloc(&dy, (size_t)n)) { (void)hipFree(dx); return rc; }
+    int rc = VBNMF_OK;
+    hipError_t he = hipMemcpy(dx, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice);
+    if (he == hipSuccess && n > 0) {
+        hipLaunchKernelGGL(k_test_special, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, kind, n, dx, dy);
+        he = hipGetLastError();
+    }
+    if (he == hipSuccess) he = hipMemcpy(y, dy, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
+    if (he != hipSuccess) rc = fail(VBNMF_ERR_HIP, "special-function test kernel failed: %s", hipGetErrorString(he));
+    (void)hipFree(dx); (void)hipFree(dy);
+    return rc;
 }
 
 // ---------------------------------------------------------------- stateless forms

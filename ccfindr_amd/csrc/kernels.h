@@ -55,47 +55,6 @@ struct SweepSide {
     int32_t n_wg;
 };
 
-// ln(x) for finite x > 0 (also subnormal); NaN propagates; x == 0 is not special-cased (the
-// sweep has already turned such an entry into NaN through x / wth).  The
-// argument reduction and degree-7 minimax polynomial in s^2, s = f/(2+f), are the
-// classical ones (x = 2^k (1+f), sqrt(1/2) <= 1+f < sqrt(2)); < 1 ulp, checked against
-// mpmath in tests.  Branch-free so the sweep's inner loop stays one basic block
-// (ocml's log costs ~95 instructions in double-double; this is ~35).
-__device__ __forceinline__ double dev_log(double x)
-{
-    int k = __builtin_amdgcn_frexp_exp(x);
-    double m = __builtin_amdgcn_frexp_mant(x);            // [0.5, 1)
-    const bool lo = m < 0.70710678118654752440;
-    m = lo ? m + m : m;
-    k = lo ? k - 1 : k;
-    const double f = m - 1.0;
-    const double d = 2.0 + f;
-    double rc = __builtin_amdgcn_rcp(d);
-    rc = fma(fma(-d, rc, 1.0), rc, rc);
-    rc = fma(fma(-d, rc, 1.0), rc, rc);
-    double s = f * rc;
-    s = fma(fma(-d, s, f), rc, s);
-    const double z = s * s, w = z * z;
-    const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
-    const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01), 6.666666666666735130e-01);
-    const double Rp = t1 + t2;
-    const double hfsq = 0.5 * f * f;
-    const double dk = (double)k;
-    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
-    return dk * ln2_hi - ((hfsq - (s * (hfsq + Rp) + dk * ln2_lo)) - f);
-}
-
-// x / w for finite w of ordinary magnitude: reciprocal seed, two Newton steps, one residual
-// correction (no range scaling: wth = sum_k lw*lh is far from the exponent limits).
-__device__ __forceinline__ double dev_div(double x, double w)
-{
-    double rc = __builtin_amdgcn_rcp(w);
-    rc = fma(fma(-w, rc, 1.0), rc, rc);
-    rc = fma(fma(-w, rc, 1.0), rc, rc);
-    const double q = x * rc;
-    return fma(fma(-w, q, x), rc, q);
-}
-
 template <int R>
 struct SweepRegs {
     double F[R];
@@ -276,65 +235,98 @@ __global__ __launch_bounds__(NT) void k_sweep(const SweepSide A, const SweepSide
     sweep_side<R, WIDE, false, NT>(B, ldsG);     // lanes own cells: statistics sh
 }
 
-// out[major][k] = sum over the major's tasks (fixed order) of part[task][k]
-__device__ __forceinline__ double task_sum(const double *__restrict__ part, const int32_t *__restrict__ inv_ptr,
-                                           const uint32_t *__restrict__ inv_task, int64_t M, int R, int k)
+// ------------------------------------------------------------------------------------
+// Small fixed-order reductions used by the update / final kernels.
+// ------------------------------------------------------------------------------------
+constexpr int kUpdateBlocks = 256;     // persistent blocks of k_update / k_prime (one per CU)
+constexpr int kUpdateThreads = 1024;
+
+__device__ __forceinline__ double wave_sum(double v)
 {
-    double s = 0.0;
-    for (int q = inv_ptr[M]; q < inv_ptr[M + 1]; q++) s += part[(size_t)inv_task[q] * R + k];
-    return s;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d, 64);
+    return v;                                     // valid in lane 0
+}
+
+// Column sums of a block-partials table bp[nb][ncol] (nb <= 256) into out[0..ncol) (LDS or
+// global): wave w takes columns w, w+nwaves, ...; lane l adds rows l, l+64, ... in order.
+__device__ __forceinline__ void bp_colsums(const double *__restrict__ bp, int nb, int ncol, double *out, int nthreads)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = nthreads >> 6;
+    for (int c = wave; c < ncol; c += nw) {
+        double s = 0.0;
+        for (int b = lane; b < nb; b += 64) s += bp[(size_t)b * ncol + c];
+        s = wave_sum(s);
+        if (lane == 0) out[c] = s;
+    }
 }
 
 // ------------------------------------------------------------------------------------
-// Posterior update of one factor (both sides share it).  One thread per (major, k).
-//   s   = acc[major][k], or the sum of the major's task partials (inv_ptr != null)
+// Posterior update of one factor (both sides share it).  256 persistent blocks; thread
+// (row_sub, k) walks its block's majors with a fixed k.
+//   s   = acc[major][k] (dense), or the sum of the major's task partials (inv_ptr != null)
 //   al  = a + l_old * s                     :38-39 / :48-49
 //   be  = a/b + other[k]                    :40-43 (rowSums of the incoming eh) / :50-53 (colSums of the NEW ew)
 //   e   = al/be ; d = al/be/be              :44,46 / :54,56
 //   l   = max(exp(psi(al))/be, fudge)       :58-65
 //   term= -(a/b) e + lga + al (1 - log be) + lgamma(al)     :82-89
-// Block partials (fixed-order tree over the block's rows): bp[block][0..R) = sum e per k,
-// bp[block][R] = sum term, bp[block][R+1] = sum log l.
+// other[k] is either given (other_nb == 0) or is the column sum of the OTHER side's block
+// partials other_bp[other_nb][R+2], reduced here in the prologue.
+// Block partials out: bp[block][0..R) = sum e per k, bp[block][R] = sum term, bp[block][R+1] = sum log l.
 // ------------------------------------------------------------------------------------
 template <int R>
-__global__ __launch_bounds__(256) void k_update(const double *__restrict__ acc, const int32_t *__restrict__ inv_ptr,
-                                                const uint32_t *__restrict__ inv_task, int64_t nmaj, int r,
-                                                const double *__restrict__ other, double a, double b, double lga,
-                                                double fudge, double *__restrict__ l, double *__restrict__ ll,
-                                                double *__restrict__ e, double *__restrict__ d, double *__restrict__ bp)
+__global__ __launch_bounds__(kUpdateThreads) void k_update(
+    const double *__restrict__ acc, const int32_t *__restrict__ inv_ptr, const uint32_t *__restrict__ inv_task,
+    int64_t nmaj, int r, const double *__restrict__ other, const double *__restrict__ other_bp, int other_nb,
+    double a, double b, double lga, double fudge,
+    double *__restrict__ l, double *__restrict__ ll, double *__restrict__ e, double *__restrict__ d, double *__restrict__ bp)
 {
-    constexpr int RB = 256 / R;                  // rows per block
-    __shared__ double s_e[256], s_t[256], s_l[256];
+    constexpr int RB = kUpdateThreads / R;       // majors per pass
+    __shared__ double s_other[R + 2];
+    __shared__ double s_e[kUpdateThreads], s_t[kUpdateThreads], s_l[kUpdateThreads];
     const int t = threadIdx.x;
+    if (other_nb > 0) bp_colsums(other_bp, other_nb, R + 2, s_other, kUpdateThreads);
+    else if (t < R) s_other[t] = other[t];
+    __syncthreads();
+
     const int row = t / R, k = t - row * R;
-    const int64_t M = (int64_t)blockIdx.x * RB + row;
+    const int64_t per = (nmaj + gridDim.x - 1) / gridDim.x;
+    const int64_t m0 = (int64_t)blockIdx.x * per, m1 = min(nmaj, m0 + per);
+    const double be = a / b + s_other[k < R ? k : 0];
+    const double lbe = log(be);
     double ve = 0.0, vt = 0.0, vl = 0.0;
-    if (row < RB && M < nmaj) {
-        const size_t o = (size_t)M * R + k;
-        if (k < r) {
-            const double s = inv_ptr ? task_sum(acc, inv_ptr, inv_task, M, R, k) : acc[o];
-            const double al = a + l[o] * s;
-            const double be = a / b + other[k];
-            ve = al / be;
-            const double dv = al / be / be;
-            const double tmp = exp(dev_digamma(al)) / be;
-            const double ln = (tmp > fudge ? tmp : fudge);
-            const double lg = log(ln);
-            vt = -(a / b) * ve + lga + al * (1.0 - log(be)) + dev_lgamma(al);
-            vl = lg;
-            l[o] = ln; ll[o] = ln * lg; e[o] = ve; d[o] = dv;
-        } else {
-            l[o] = 0.0; ll[o] = 0.0; e[o] = 0.0; d[o] = 0.0;
+    if (row < RB) {
+        for (int64_t M = m0 + row; M < m1; M += RB) {
+            const size_t o = (size_t)M * R + k;
+            if (k < r) {
+                double s;
+                if (inv_ptr) {
+                    s = 0.0;
+                    for (int q = inv_ptr[M]; q < inv_ptr[M + 1]; q++) s += acc[(size_t)inv_task[q] * R + k];
+                } else s = acc[o];
+                const double al = a + l[o] * s;
+                const double ev = al / be;
+                const double dv = al / be / be;
+                double psi, lgam;
+                dev_psi_lgamma(al, &psi, &lgam);
+                if (!(al > 0.0)) { psi = __builtin_nan(""); lgam = __builtin_nan(""); }
+                const double tmp = exp(psi) / be;
+                const double ln = (tmp > fudge ? tmp : fudge);
+                const double lg = log(ln);
+                ve += ev;
+                vt += -(a / b) * ev + lga + al * (1.0 - lbe) + lgam;
+                vl += lg;
+                l[o] = ln; ll[o] = ln * lg; e[o] = ev; d[o] = dv;
+            } else {
+                l[o] = 0.0; ll[o] = 0.0; e[o] = 0.0; d[o] = 0.0;
+            }
         }
     }
     s_e[t] = ve; s_t[t] = vt; s_l[t] = vl;
     __syncthreads();
-    constexpr int P2 = (RB <= 1) ? 1 : (RB <= 2) ? 2 : (RB <= 4) ? 4 : (RB <= 8) ? 8 : (RB <= 16) ? 16
-                     : (RB <= 32) ? 32 : (RB <= 64) ? 64 : 128;
+    constexpr int P2 = (RB <= 32) ? 32 : (RB <= 64) ? 64 : (RB <= 128) ? 128 : (RB <= 256) ? 256 : 512;
     for (int h = P2 / 2; h >= 1; h >>= 1) {
-        if (row < h && row + h < RB) {
-            s_e[t] += s_e[t + h * R]; s_t[t] += s_t[t + h * R]; s_l[t] += s_l[t + h * R];
-        }
+        if (row < h && row + h < RB) { s_e[t] += s_e[t + h * R]; s_t[t] += s_t[t + h * R]; s_l[t] += s_l[t + h * R]; }
         __syncthreads();
     }
     double *o = bp + (size_t)blockIdx.x * (R + 2);
@@ -349,25 +341,27 @@ __global__ __launch_bounds__(256) void k_update(const double *__restrict__ acc, 
 // State load (set_state): ll = l*log(l) and the block partials of e's column sums, same
 // bp layout as k_update (term and log-sum columns are written as 0).
 template <int R>
-__global__ __launch_bounds__(256) void k_prime(int64_t nmaj, int r, const double *__restrict__ l,
-                                               double *__restrict__ ll, const double *__restrict__ e,
-                                               double *__restrict__ bp)
+__global__ __launch_bounds__(kUpdateThreads) void k_prime(int64_t nmaj, int r, const double *__restrict__ l,
+                                                          double *__restrict__ ll, const double *__restrict__ e,
+                                                          double *__restrict__ bp)
 {
-    constexpr int RB = 256 / R;
-    __shared__ double s_e[256];
+    constexpr int RB = kUpdateThreads / R;
+    __shared__ double s_e[kUpdateThreads];
     const int t = threadIdx.x;
     const int row = t / R, k = t - row * R;
-    const int64_t M = (int64_t)blockIdx.x * RB + row;
+    const int64_t per = (nmaj + gridDim.x - 1) / gridDim.x;
+    const int64_t m0 = (int64_t)blockIdx.x * per, m1 = min(nmaj, m0 + per);
     double ve = 0.0;
-    if (row < RB && M < nmaj) {
-        const size_t o = (size_t)M * R + k;
-        if (k < r) { const double v = l[o]; ll[o] = v * log(v); if (e) ve = e[o]; }
-        else ll[o] = 0.0;
+    if (row < RB) {
+        for (int64_t M = m0 + row; M < m1; M += RB) {
+            const size_t o = (size_t)M * R + k;
+            if (k < r) { const double v = l[o]; ll[o] = v * log(v); if (e) ve += e[o]; }
+            else ll[o] = 0.0;
+        }
     }
     s_e[t] = ve;
     __syncthreads();
-    constexpr int P2 = (RB <= 1) ? 1 : (RB <= 2) ? 2 : (RB <= 4) ? 4 : (RB <= 8) ? 8 : (RB <= 16) ? 16
-                     : (RB <= 32) ? 32 : (RB <= 64) ? 64 : 128;
+    constexpr int P2 = (RB <= 32) ? 32 : (RB <= 64) ? 64 : (RB <= 128) ? 128 : (RB <= 256) ? 256 : 512;
     for (int h = P2 / 2; h >= 1; h >>= 1) {
         if (row < h && row + h < RB) s_e[t] += s_e[t + h * R];
         __syncthreads();
@@ -378,41 +372,10 @@ __global__ __launch_bounds__(256) void k_prime(int64_t nmaj, int r, const double
 }
 
 // ------------------------------------------------------------------------------------
-// Fixed-order reductions.  Block c < ncols sums column c of a row-major [count][stride]
-// table into dst[c]; block ncols (if vsrc) sums the vector vsrc[0..vcount) into *vdst.
-// Thread t adds elements t, t+256, ... in order, then a binary tree over the 256 threads.
+// Cell-partitioned runs: the gene-side statistics and the cell-side scalars go into the
+// reduce buffer [swsum n*R | tail R+4] that the caller all-reduces.
 // ------------------------------------------------------------------------------------
-struct ReduceArgs {
-    const double *src; int64_t count; int64_t stride; int ncols; double *dst;
-    const double *vsrc; int64_t vcount; double *vdst;
-    double *cdst; double cval;        // optional constant to (re)write beside the sums
-};
-
-__global__ __launch_bounds__(256) void k_reduce(const ReduceArgs a)
-{
-    __shared__ double sm[256];
-    const int t = threadIdx.x;
-    const int c = blockIdx.x;
-    double s = 0.0;
-    if (c < a.ncols) {
-        for (int64_t q = t; q < a.count; q += 256) s += a.src[q * a.stride + c];
-    } else {
-        for (int64_t q = t; q < a.vcount; q += 256) s += a.vsrc[q];
-    }
-    sm[t] = s;
-    __syncthreads();
-    for (int h = 128; h >= 1; h >>= 1) {
-        if (t < h) sm[t] += sm[t + h];
-        __syncthreads();
-    }
-    if (t == 0) {
-        if (c < a.ncols) a.dst[c] = sm[0];
-        else { *a.vdst = sm[0]; if (a.cdst) *a.cdst = a.cval; }
-    }
-}
-
-// out[major][k] = sum of the major's task partials, fixed order (the gene-side statistics
-// in the form a cell-partitioned run all-reduces).
+// out[major][k] = sum of the major's task partials, fixed order.
 __global__ __launch_bounds__(256) void k_pack(const double *__restrict__ part, const int32_t *__restrict__ inv_ptr,
                                               const uint32_t *__restrict__ inv_task, int64_t nmaj, int R,
                                               double *__restrict__ out)
@@ -421,26 +384,89 @@ __global__ __launch_bounds__(256) void k_pack(const double *__restrict__ part, c
     if (e >= nmaj * R) return;
     const int64_t M = e / R;
     const int k = (int)(e - M * R);
-    out[e] = task_sum(part, inv_ptr, inv_task, M, R, k);
+    double s = 0.0;
+    for (int q = inv_ptr[M]; q < inv_ptr[M + 1]; q++) s += part[(size_t)inv_task[q] * R + k];
+    out[e] = s;
 }
 
-// Evidence and the four hyper statistics from the reduced scalars.
-//   outW : [R+2]  colSum(ew)_k, sum W-terms, sum log lw          (replicated)
-//   tail : [R+4]  rowSum(eh)_k, sum H-terms, sum log lh, data term, sum lgamma(x+1)   (summed over partitions)
-//   out  : lkh, mean log lw, mean log lh, mean ew, mean eh
-template <int R>
-__global__ void k_final(const double *__restrict__ outW, const double *__restrict__ tail, int r, double n,
-                        double m_global, double *__restrict__ out)
+// Sum of v[0..count) by one 1024-thread block: thread t adds t, t+1024, ... in order, then a tree.
+__device__ __forceinline__ double block_vec_sum(const double *__restrict__ v, int64_t count, double *sm)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double cross = 0.0, sew = 0.0, seh = 0.0;
-    for (int k = 0; k < r; k++) { cross += outW[k] * tail[k]; sew += outW[k]; seh += tail[k]; }
-    const double U = -cross - tail[R + 2] - tail[R + 3] + outW[R] + tail[R];
-    out[0] = U / (n * m_global);
-    out[1] = outW[R + 1] / (n * r);
-    out[2] = tail[R + 1] / (m_global * r);
-    out[3] = sew / (n * r);
-    out[4] = seh / (m_global * r);
+    const int t = threadIdx.x;
+    double s = 0.0;
+    for (int64_t q = t; q < count; q += 1024) s += v[q];
+    sm[t] = s;
+    __syncthreads();
+    for (int h = 512; h >= 1; h >>= 1) {
+        if (t < h) sm[t] += sm[t + h];
+        __syncthreads();
+    }
+    return sm[0];
+}
+
+// tail = [rowSum(eh)_k (R) | sum H-terms | sum log lh | data term | sum lgamma(x+1)] of THIS partition.
+__global__ __launch_bounds__(1024) void k_tail(const double *__restrict__ bpH, int nbH, int R,
+                                               const double *__restrict__ epart, int64_t nepart, double lgx,
+                                               double *__restrict__ tail)
+{
+    __shared__ double sm[1024];
+    bp_colsums(bpH, nbH, R + 2, tail, 1024);
+    const double data = block_vec_sum(epart, nepart, sm);
+    if (threadIdx.x == 0) { tail[R + 2] = data; tail[R + 3] = lgx; }
+}
+
+// Evidence and the four hyper statistics.  One block.
+//   W side : colSum(ew)_k, sum W-terms, sum log lw  = column sums of bpW (replicated in every partition)
+//   tail   : as k_tail writes it; either given (summed over partitions by the caller) or, when
+//            tail == nullptr, formed here from bpH / epart / lgx (single-GPU path, no extra launch).
+//   out    : lkh, mean log lw, mean log lh, mean ew, mean eh, then out[7] = seq (the host polls it).
+template <int R>
+__global__ __launch_bounds__(1024) void k_final(const double *__restrict__ bpW, int nbW, const double *__restrict__ tail_in,
+                                                const double *__restrict__ bpH, int nbH,
+                                                const double *__restrict__ epart, int64_t nepart, double lgx,
+                                                int r, double n, double m_global, double seq, double *__restrict__ out,
+                                                double *__restrict__ out_host)
+{
+    __shared__ double sW[R + 2], sT[R + 4];
+    __shared__ double sm[1024];
+    bp_colsums(bpW, nbW, R + 2, sW, 1024);
+    if (tail_in) {
+        if (threadIdx.x < R + 4) sT[threadIdx.x] = tail_in[threadIdx.x];
+        __syncthreads();
+    } else {
+        bp_colsums(bpH, nbH, R + 2, sT, 1024);
+        const double data = block_vec_sum(epart, nepart, sm);
+        if (threadIdx.x == 0) { sT[R + 2] = data; sT[R + 3] = lgx; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        double cross = 0.0, sew = 0.0, seh = 0.0;
+        for (int k = 0; k < r; k++) { cross += sW[k] * sT[k]; sew += sW[k]; seh += sT[k]; }
+        const double U = -cross - sT[R + 2] - sT[R + 3] + sW[R] + sT[R];
+        double o[5];
+        o[0] = U / (n * m_global);
+        o[1] = sW[R + 1] / (n * r);
+        o[2] = sT[R + 1] / (m_global * r);
+        o[3] = sew / (n * r);
+        o[4] = seh / (m_global * r);
+        for (int q = 0; q < 5; q++) { out[q] = o[q]; out_host[q] = o[q]; }
+        __threadfence_system();
+        reinterpret_cast<volatile double *>(out_host)[7] = seq;
+    }
+}
+
+// Device-side evaluation of the special functions, for tests (tests/test_gpu_special.py).
+__global__ void k_test_special(int kind, int64_t n, const double *__restrict__ x, double *__restrict__ y)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double psi, lg;
+    switch (kind) {
+        case 0: y[i] = dev_log(x[i]); break;
+        case 1: dev_psi_lgamma(x[i], &psi, &lg); y[i] = psi; break;
+        case 2: dev_psi_lgamma(x[i], &psi, &lg); y[i] = lg; break;
+        default: y[i] = dev_div(1.0, x[i]); break;
+    }
 }
 
 }  // namespace vbnmf

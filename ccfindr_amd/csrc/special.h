@@ -1,49 +1,130 @@
-// special.h -- fp64 digamma and log-gamma for gfx950 device code.
+// special.h -- fp64 special functions for gfx950 device code: ln, digamma, log-gamma.
 //
-// The reference evaluates these through GSL (gsl_sf_psi, gsl_sf_lngamma; reference
-// src/vbnmf_update.cpp:59,63,82,85,87,89).  HIP has no digamma, and the engine only needs
-// positive arguments (alw = aw + sw >= aw > 0), so both are written out here:
-// upward recurrence to x >= 10, then the Stirling / Bernoulli asymptotic series, whose
-// first omitted term is < 1e-16 there.
+// The reference evaluates psi and ln Gamma through GSL (gsl_sf_psi, gsl_sf_lngamma; reference
+// src/vbnmf_update.cpp:59,63,82,85,87,89).  HIP has no digamma, ocml's log costs ~95
+// double-double instructions, and the engine only needs positive arguments
+// (alw = aw + sw >= aw > 0), so all three are written out here, branch-free.
+//
+// The functions are __host__ __device__ so the same source can be checked on the CPU build
+// against mpmath (tests/test_special_cpu.py through vbnmf_test_special); the device build is
+// checked on the GPU (tests/test_gpu_special.py).
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cmath>
+
 namespace vbnmf {
 
-// psi(x), x > 0.  |error| <= ~1e-15 * max(1, |psi|) (checked against mpmath in tests).
-__device__ __forceinline__ double dev_digamma(double x)
+// ---- building blocks that have a gfx950 instruction on the device and a libm form on the host
+__host__ __device__ __forceinline__ double sp_rcp_seed(double x)
 {
-    if (!(x > 0.0)) return __builtin_nan("");
-    double s = 0.0;
-    while (x < 10.0) { s -= 1.0 / x; x += 1.0; }
-    const double xi = 1.0 / x, y = xi * xi;
-    double ser = 1.0 / 12;                       // B_14/14 = 1/12
-    ser = 691.0 / 32760 - y * ser;
-    ser = 1.0 / 132 - y * ser;
-    ser = 1.0 / 240 - y * ser;
-    ser = 1.0 / 252 - y * ser;
-    ser = 1.0 / 120 - y * ser;
-    ser = 1.0 / 12 - y * ser;
-    return s + log(x) - 0.5 * xi - y * ser;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcp(x);
+#else
+    double r = 1.0 / x;                        // deliberately coarsened to ~24 bits: the Newton steps must cope
+    unsigned long long u;
+    __builtin_memcpy(&u, &r, 8);
+    u &= ~((1ULL << 29) - 1);
+    __builtin_memcpy(&r, &u, 8);
+    return r;
+#endif
+}
+__host__ __device__ __forceinline__ double sp_frexp(double x, int *k)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    *k = __builtin_amdgcn_frexp_exp(x);
+    return __builtin_amdgcn_frexp_mant(x);
+#else
+    return std::frexp(x, k);
+#endif
 }
 
-// ln Gamma(x), x > 0.  |error| <= ~4e-15 * max(1, |lnGamma|).
-__device__ __forceinline__ double dev_lgamma(double x)
+// 1/w: reciprocal seed plus Newton steps (quadratic: 3 steps take even a 2^-12 seed to < 2^-53).
+__host__ __device__ __forceinline__ double sp_rcp(double w)
 {
-    if (!(x > 0.0)) return (x == 0.0) ? __builtin_inf() : __builtin_nan("");
-    double p = 1.0;
-    while (x < 10.0) { p *= x; x += 1.0; }
-    const double xi = 1.0 / x, y = xi * xi;
-    double ser = 1.0 / 156;
-    ser = 691.0 / 360360 - y * ser;
-    ser = 1.0 / 1188 - y * ser;
-    ser = 1.0 / 1680 - y * ser;
-    ser = 1.0 / 1260 - y * ser;
-    ser = 1.0 / 360 - y * ser;
-    ser = 1.0 / 12 - y * ser;
+    double rc = sp_rcp_seed(w);
+    rc = fma(fma(-w, rc, 1.0), rc, rc);
+    rc = fma(fma(-w, rc, 1.0), rc, rc);
+#if !defined(__HIP_DEVICE_COMPILE__)
+    rc = fma(fma(-w, rc, 1.0), rc, rc);
+#endif
+    return rc;
+}
+
+// x / w for finite w of ordinary magnitude: reciprocal + one residual correction (no range
+// scaling: the engine's divisors are far from the exponent limits).
+__host__ __device__ __forceinline__ double dev_div(double x, double w)
+{
+    const double rc = sp_rcp(w);
+    const double q = x * rc;
+    return fma(fma(-w, q, x), rc, q);
+}
+
+// ln(x) for finite x > 0 (also subnormal); NaN propagates; x == 0 is not special-cased (the
+// sweep has already turned such an entry into NaN through x / wth).  x = 2^k (1+f) with
+// sqrt(1/2) <= 1+f < sqrt(2), s = f/(2+f), ln(1+f) = 2s + s*R(s^2) with the classical degree-7
+// minimax R; < 1 ulp.  Branch-free so the sweep's inner loop stays one basic block.
+__host__ __device__ __forceinline__ double dev_log(double x)
+{
+    int k;
+    double m = sp_frexp(x, &k);                           // [0.5, 1)
+    const bool lo = m < 0.70710678118654752440;
+    m = lo ? m + m : m;
+    k = lo ? k - 1 : k;
+    const double f = m - 1.0;
+    const double d = 2.0 + f;
+    const double rc = sp_rcp(d);
+    double s = f * rc;
+    s = fma(fma(-d, s, f), rc, s);
+    const double z = s * s, w = z * z;
+    const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+    const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01), 6.666666666666735130e-01);
+    const double Rp = t1 + t2;
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)k;
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    return dk * ln2_hi - ((hfsq - (s * (hfsq + Rp) + dk * ln2_lo)) - f);
+}
+
+// psi(x) and ln Gamma(x) together, x > 0 (x up to ~1e25; the engine's arguments are count sums).
+// Both use the same upward shift by 10,
+//     psi(x)     = psi(x+10)      - D'(x)/D(x)
+//     lnGamma(x) = lnGamma(x+10)  - ln D(x),          D(x) = x (x+1) ... (x+9),
+// then the Stirling / Bernoulli asymptotic series at y = x+10 >= 10, whose first omitted terms
+// are < 5e-17.  One division, two logs, no loop, no branch.
+//   |psi error|     <= ~2e-15 * max(1, |psi|)
+//   |lnGamma error| <= ~1e-14 * max(1, |lnGamma|)   (two ~17.5-sized terms cancel near x = 1, 2)
+__host__ __device__ __forceinline__ void dev_psi_lgamma(double x, double *psi, double *lgam)
+{
+    double D = x, Dp = 1.0;                               // D and dD/dx, built factor by factor
+#pragma unroll
+    for (int i = 1; i < 10; i++) {
+        const double t = x + (double)i;
+        Dp = fma(Dp, t, D);
+        D = D * t;
+    }
+    const double y = x + 10.0;
+    const double ly = dev_log(y);
+    const double yi = sp_rcp(y), y2 = yi * yi;
+    // psi(y) = ln y - 1/(2y) - sum B_2k / (2k y^2k)
+    double sp = 1.0 / 12;
+    sp = fma(-y2, sp, 691.0 / 32760);
+    sp = fma(-y2, sp, 1.0 / 132);
+    sp = fma(-y2, sp, 1.0 / 240);
+    sp = fma(-y2, sp, 1.0 / 252);
+    sp = fma(-y2, sp, 1.0 / 120);
+    sp = fma(-y2, sp, 1.0 / 12);
+    *psi = (ly - 0.5 * yi - y2 * sp) - dev_div(Dp, D);
+    // lnGamma(y) = (y - 1/2) ln y - y + ln(2 pi)/2 + sum B_2k / (2k (2k-1) y^(2k-1))
+    double sg = 1.0 / 156;
+    sg = fma(-y2, sg, 691.0 / 360360);
+    sg = fma(-y2, sg, 1.0 / 1188);
+    sg = fma(-y2, sg, 1.0 / 1680);
+    sg = fma(-y2, sg, 1.0 / 1260);
+    sg = fma(-y2, sg, 1.0 / 360);
+    sg = fma(-y2, sg, 1.0 / 12);
     const double half_log_2pi = 0.91893853320467274178;
-    double st = (x - 0.5) * log(x) - x + half_log_2pi + xi * ser;
-    return st - log(p);
+    *lgam = (((y - 0.5) * ly - y) + half_log_2pi + yi * sg) - dev_log(D);
 }
 
 }  // namespace vbnmf

@@ -205,6 +205,15 @@ int vbnmf_layout_build(const vbnmf_matrix *X, int64_t col_begin, int64_t col_end
                        int32_t r, vbnmf_layout **out, vbnmf_layout_view *view);
 void vbnmf_layout_destroy(vbnmf_layout *L);
 
+/* ---------------------------------------------------------------------------------
+ * Test hooks: the library's own fp64 ln / digamma / lnGamma (which stand in for libm's log
+ * and GSL's gsl_sf_psi / gsl_sf_lngamma, reference src/vbnmf_update.cpp:59,63,73,81-89),
+ * evaluated on the host build and on the device, so tests can check them against mpmath.
+ * kind: 0 = ln(x), 1 = psi(x), 2 = lnGamma(x), 3 = 1/x.
+ * --------------------------------------------------------------------------------- */
+int vbnmf_test_special_host(int32_t kind, int64_t n, const double *x, double *y);
+int vbnmf_test_special_device(int32_t kind, int64_t n, const double *x, double *y);
+
 #ifdef __cplusplus
 }
 #endif
