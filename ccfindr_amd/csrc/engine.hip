@@ -73,7 +73,7 @@ struct vbnmf_engine {
     DeviceSide A, B;                  // A: lanes own genes ; B: lanes own cells
     double *lw = nullptr, *llw = nullptr, *ew = nullptr, *dw = nullptr;
     double *lh = nullptr, *llh = nullptr, *eh = nullptr, *dh = nullptr;
-    double *epart = nullptr;          // [A.n_slices + B.n_slices]
+    double *epart = nullptr;          // [2 * n_wg] evidence partials: gene side, then cell side
     double *bpW = nullptr, *bpH = nullptr;   // [kUpdateBlocks][R+2] block partials of the two updates
     double *red = nullptr;            // [n*R | R+4]  (partitioned engines only use the first part)
     int64_t red_count = 0;
@@ -169,7 +169,7 @@ int launch_sweep_r(vbnmf_engine *e, const SweepSide &a, const SweepSide &b)
 int launch_sweep(vbnmf_engine *e)
 {
     SweepSide a = sweep_side_args(e, e->A, true, e->epart);
-    SweepSide b = sweep_side_args(e, e->B, false, e->epart + e->A.n_slices);
+    SweepSide b = sweep_side_args(e, e->B, false, e->epart + e->n_wg);
     if (e->timing) { HIPCHECK(hipEventRecord(e->ev0, e->stream)); }
     int rc = VBNMF_ERR_BAD_ARG;
     switch (e->R) {
@@ -228,7 +228,7 @@ int launch_prime(vbnmf_engine *e, bool gene_side)
 int launch_final(vbnmf_engine *e)
 {
     const double *tail = e->partitioned ? e->red + (size_t)e->n * e->R : nullptr;
-    const int64_t nep = e->A.n_slices + e->B.n_slices;
+    const int64_t nep = 2 * (int64_t)e->n_wg;
     e->seq += 1.0;
     switch (e->R) {
 #define X(RR) case RR: hipLaunchKernelGGL((k_final<RR>), dim3(1), dim3(1024), 0, e->stream, e->bpW, kUpdateBlocks, tail, e->bpH, kUpdateBlocks, e->epart, nep, e->lgx, e->r, (double)e->n, (double)e->m_global, e->seq, e->d_out, e->h_out_dev); break;
@@ -247,7 +247,7 @@ int launch_pack(vbnmf_engine *e)
     hipLaunchKernelGGL(k_pack, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, e->stream, e->A.part, e->A.inv_ptr, e->A.inv_task, e->n, e->R, e->red);
     HIPCHECK(hipGetLastError());
     hipLaunchKernelGGL(k_tail, dim3(1), dim3(1024), 0, e->stream, e->bpH, kUpdateBlocks, e->R, e->epart,
-                       (int64_t)(e->A.n_slices + e->B.n_slices), e->lgx, e->red + cnt);
+                       2 * (int64_t)e->n_wg, e->lgx, e->red + cnt);
     HIPCHECK(hipGetLastError());
     return VBNMF_OK;
 }
@@ -387,7 +387,7 @@ int vbnmf_engine_create_part(const vbnmf_matrix *X, int64_t cb, int64_t ce, int6
     e->red_count = (int64_t)nR + e->R + 4;
     if ((rc = dev_alloc(&e->lw, nR)) || (rc = dev_alloc(&e->llw, nR)) || (rc = dev_alloc(&e->ew, nR)) || (rc = dev_alloc(&e->dw, nR)) ||
         (rc = dev_alloc(&e->lh, mR)) || (rc = dev_alloc(&e->llh, mR)) || (rc = dev_alloc(&e->eh, mR)) || (rc = dev_alloc(&e->dh, mR)) ||
-        (rc = dev_alloc(&e->epart, (size_t)(e->A.n_slices + e->B.n_slices))) ||
+        (rc = dev_alloc(&e->epart, 2 * (size_t)e->n_wg)) ||
         (rc = dev_alloc(&e->bpW, bpn)) || (rc = dev_alloc(&e->bpH, bpn)) ||
         (rc = dev_alloc(&e->red, (size_t)e->red_count)) || (rc = dev_alloc(&e->d_out, 8)))
         return bail(rc);

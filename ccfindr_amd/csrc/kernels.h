@@ -48,7 +48,7 @@ struct SweepSide {
     const double *llF;             // [n_major][R]  F * log F
     const double *G;               // [n_minor][R]  factor gathered through LDS
     double *part;                  // [n_slices*64][R] partial statistics per task
-    double *epart;                 // [n_slices] evidence partials
+    double *epart;                 // [n_wg] evidence partials, one per workgroup
     int32_t n_minor;
     int32_t block_width;
     int32_t logterm;               // this side also accumulates sum x*log(wth)
@@ -125,6 +125,7 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
     const int nwg = S.n_wg;
     const int wg = (nwg % 8 == 0) ? (int)(blockIdx.x % 8) * (nwg / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
     const int seg0 = S.wg_seg0[wg], seg1 = S.wg_seg0[wg + 1];
+    double ev_wave = 0.0;                                  // this wave's evidence contributions, in slice order
     for (int seg = seg0; seg < seg1; seg++) {
         const int blk = S.seg_block[seg];
         const int m0 = blk * S.block_width;
@@ -222,8 +223,18 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
             }
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) ev += __shfl_down(ev, d, 64);
-            if (lane == 0) S.epart[s] = ev;
+            ev_wave += ev;                                 // meaningful in lane 0
         }
+    }
+    // one evidence partial per workgroup: the waves' sums added in wave order
+    __syncthreads();                                       // all LDS reads of the last block are done
+    double *sm = reinterpret_cast<double *>(ldsG);
+    if (lane == 0) sm[wave] = ev_wave;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < NT / 64; w++) t += sm[w];
+        S.epart[wg] = t;
     }
 }
 
@@ -233,6 +244,25 @@ __global__ __launch_bounds__(NT) void k_sweep(const SweepSide A, const SweepSide
     extern __shared__ double2 ldsG[];
     sweep_side<R, WIDE, true, NT>(A, ldsG);      // lanes own genes: statistics sw + the sum x log(wth)
     sweep_side<R, WIDE, false, NT>(B, ldsG);     // lanes own cells: statistics sh
+}
+
+// Sum of one major's task partials for column k, in the inverse index's fixed order.  The
+// task ids and then the partials are loaded eight at a time so the loads overlap.
+__device__ __forceinline__ double task_sum(const double *__restrict__ part, const uint32_t *__restrict__ inv_task,
+                                           int q0, int q1, int R, int k)
+{
+    double s = 0.0;
+    for (int q = q0; q < q1; q += 8) {
+        uint32_t id[8];
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) id[u] = inv_task[min(q + u, q1 - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = part[(size_t)id[u] * R + k];
+#pragma unroll
+        for (int u = 0; u < 8; u++) s += (q + u < q1) ? v[u] : 0.0;
+    }
+    return s;
 }
 
 // ------------------------------------------------------------------------------------
@@ -299,11 +329,7 @@ __global__ __launch_bounds__(kUpdateThreads) void k_update(
         for (int64_t M = m0 + row; M < m1; M += RB) {
             const size_t o = (size_t)M * R + k;
             if (k < r) {
-                double s;
-                if (inv_ptr) {
-                    s = 0.0;
-                    for (int q = inv_ptr[M]; q < inv_ptr[M + 1]; q++) s += acc[(size_t)inv_task[q] * R + k];
-                } else s = acc[o];
+                const double s = inv_ptr ? task_sum(acc, inv_task, inv_ptr[M], inv_ptr[M + 1], R, k) : acc[o];
                 const double al = a + l[o] * s;
                 const double ev = al / be;
                 const double dv = al / be / be;
@@ -384,9 +410,7 @@ __global__ __launch_bounds__(256) void k_pack(const double *__restrict__ part, c
     if (e >= nmaj * R) return;
     const int64_t M = e / R;
     const int k = (int)(e - M * R);
-    double s = 0.0;
-    for (int q = inv_ptr[M]; q < inv_ptr[M + 1]; q++) s += part[(size_t)inv_task[q] * R + k];
-    out[e] = s;
+    out[e] = task_sum(part, inv_task, inv_ptr[M], inv_ptr[M + 1], R, k);
 }
 
 // Sum of v[0..count) by one 1024-thread block: thread t adds t, t+1024, ... in order, then a tree.
