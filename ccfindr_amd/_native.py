@@ -13,7 +13,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvbnmf_hip.so")
+# VBNMF_LIB overrides the path (A/B runs of experimental builds); the default is the in-tree build.
+LIB_PATH = os.environ.get("VBNMF_LIB") or os.path.join(_HERE, "lib", "libvbnmf_hip.so")
 
 c_double_p = ctypes.POINTER(ctypes.c_double)
 c_int32_p = ctypes.POINTER(ctypes.c_int32)
@@ -37,9 +38,10 @@ class LayoutView(ctypes.Structure):
         ("side", ctypes.c_int32), ("wide", ctypes.c_int32),
         ("n_major", ctypes.c_int64), ("n_minor", ctypes.c_int64),
         ("block_width", ctypes.c_int32), ("n_blocks", ctypes.c_int32), ("max_len", ctypes.c_int32), ("n_wg", ctypes.c_int32),
+        ("n_waves", ctypes.c_int32),
         ("n_tasks", ctypes.c_int64), ("n_slices", ctypes.c_int64), ("n_slots", ctypes.c_int64), ("n_segs", ctypes.c_int64),
         ("task_major", c_uint32_p), ("slice_width", c_int32_p), ("slice_off", c_int64_p), ("slice_block", c_int32_p),
-        ("seg_block", c_int32_p), ("seg_slice0", c_int32_p), ("wg_seg0", c_int32_p),
+        ("seg_block", c_int32_p), ("wg_seg0", c_int32_p), ("segwave_ptr", c_int32_p), ("segwave_slice", c_int32_p),
         ("inv_ptr", c_int32_p), ("inv_task", c_uint32_p),
         ("packed", c_uint32_p), ("wide_idx", c_uint32_p), ("wide_val", c_double_p),
     ]
@@ -74,6 +76,7 @@ SIGNATURES = {
     "vbnmf_engine_timing_enable": (ctypes.c_int, [_VP, _I32]),
     "vbnmf_engine_timing_get": (ctypes.c_int, [_VP, c_double_p, c_int64_p]),
     "vbnmf_engine_layout_info": (ctypes.c_int, [_VP] + [c_int64_p] * 6),
+    "vbnmf_engine_debug_times": (ctypes.c_int, [_VP, ctypes.POINTER(ctypes.c_uint64), _I64, c_int32_p, c_int32_p]),
     "vbnmf_update_dense": (ctypes.c_int, [_I64, _I64, _I32, c_double_p, c_double_p, c_double_p, c_double_p]
                            + [_D] * 5 + [c_double_p] * 7),
     "vbnmf_update_csc": (ctypes.c_int, [_I64, _I64, _I32, c_int32_p, c_int32_p, c_double_p,

@@ -39,10 +39,12 @@ double sum_lgamma_x1(const Matrix &X, int64_t cb, int64_t ce);
 // A *task* is a run of at most `max_len` stored entries of one major (gene on side 0, cell
 // on side 1) whose minors fall in one minor block; one lane of the sweep kernel owns it.
 // Tasks of a block are sorted by length (descending) and cut into *slices* of 64 (one
-// wavefront); the slice list, ordered by block, is cut into `n_wg` contiguous ranges of
-// equal cost, one per persistent workgroup; a *segment* is a run of slices of one block
-// inside one workgroup's range (the workgroup stages that block of the gathered factor in
-// LDS once per segment).
+// wavefront).  Each block's slices are dealt out in strides so that any contiguous stretch of
+// the resulting work list holds a mix of long and short slices; the list is cut into `n_wg`
+// stretches of equal cost, one per persistent workgroup; a *segment* is the part of a
+// stretch that lies in one block (the workgroup stages that block of the gathered factor in
+// LDS once per segment), and inside a segment the slices are bin-packed onto the workgroup's
+// `n_waves` waves (longest first, to the least loaded wave).
 constexpr int kLanes = 64;          // one slice = one wavefront
 constexpr int kUnroll = 4;          // entries per lane per 16-byte load
 constexpr int kWidthQuantum = 8;    // slice widths are multiples of this (two loads per loop trip)
@@ -52,15 +54,16 @@ struct Layout {
     int side = 0;                   // 0: lanes own genes, minors = cells; 1: lanes own cells, minors = genes
     bool wide = false;
     int64_t n_major = 0, n_minor = 0;
-    int32_t block_width = 0, n_blocks = 0, max_len = 0, n_wg = 0;
+    int32_t block_width = 0, n_blocks = 0, max_len = 0, n_wg = 0, n_waves = 0;
     int64_t n_tasks = 0, n_slices = 0, n_slots = 0, n_segs = 0, nnz = 0;
     std::vector<uint32_t> task_major;    // n_slices * 64 ; kIdleLane pads a block's last slice
     std::vector<int32_t> slice_width;    // n_slices ; entries per lane, multiple of 4
     std::vector<int64_t> slice_off;      // n_slices ; first slot of the slice
     std::vector<int32_t> slice_block;    // n_slices ; minor block (host-side bookkeeping / tests)
     std::vector<int32_t> seg_block;      // n_segs
-    std::vector<int32_t> seg_slice0;     // n_segs + 1
     std::vector<int32_t> wg_seg0;        // n_wg + 1
+    std::vector<int32_t> segwave_ptr;    // n_segs * n_waves + 1 : slices of (segment, wave) ...
+    std::vector<int32_t> segwave_slice;  // n_slices             : ... in processing order
     std::vector<int32_t> inv_ptr;        // n_major + 1 : tasks of each major ...
     std::vector<uint32_t> inv_task;      // n_tasks     : ... as slice*64+lane ids, in (block, position) order
     std::vector<uint32_t> packed;        // n_slots (wide == false)
@@ -72,10 +75,16 @@ struct LayoutParams {
     int32_t block_width;   // minors per LDS block
     int32_t max_len;       // longest task (entries), multiple of 4
     int32_t n_wg;          // persistent workgroups of the sweep kernel
+    int32_t n_waves;       // waves per workgroup
 };
 
 // Padded rank used on the device (even, so a factor row is a whole number of 16-byte LDS reads).
 inline int padded_rank(int r) { return (r + 1) & ~1; }
+// Bytes of one factor row in the sweep's LDS image: R doubles, padded to an odd number of 16-byte
+// bank slots so that rows congruent mod 16 (and only those) start in the same slot.
+constexpr int lds_row_bytes(int R) { return ((R / 2) | 1) * 16; }
+// LDS the sweep keeps for itself in front of the factor block (the 128-entry ln table).
+constexpr int kLdsReserveBytes = 2048;
 // Threads per workgroup of the sweep kernel at padded rank R.
 constexpr int sweep_threads(int R) { return R <= 4 ? 1024 : (R <= 10 ? 768 : 512); }
 // Default block width / task length for a side at padded rank R; n_wg <= 0 picks the default (256).

@@ -33,7 +33,7 @@ namespace {
 struct DeviceSide {
     uint32_t *packed = nullptr, *widx = nullptr, *task_major = nullptr, *inv_task = nullptr;
     double *wval = nullptr;
-    int32_t *slice_width = nullptr, *seg_block = nullptr, *seg_slice0 = nullptr, *wg_seg0 = nullptr, *inv_ptr = nullptr;
+    int32_t *slice_width = nullptr, *seg_block = nullptr, *segwave_ptr = nullptr, *segwave_slice = nullptr, *wg_seg0 = nullptr, *inv_ptr = nullptr;
     int64_t *slice_off = nullptr;
     double *part = nullptr;
     int64_t n_major = 0, n_minor = 0, n_tasks = 0, n_slices = 0, n_slots = 0;
@@ -81,6 +81,9 @@ struct vbnmf_engine {
     double *h_out = nullptr;          // pinned, device-visible [8]; [7] = sequence flag
     double *h_out_dev = nullptr;      // device address of h_out
     double seq = 0.0;
+    LogTabEntry *logtab = nullptr;    // [128] ln table of the sweep
+    unsigned long long *dbg = nullptr;   // diagnostic timestamps of the sweep (VBNMF_DEBUG_TIMES=1)
+    size_t dbg_count = 0;
     size_t lds_bytes = 0;
     bool has_state = false, stats_ready = false, step_pending = false, prime_pending = false;
     bool timing = false;
@@ -95,7 +98,7 @@ namespace {
 void free_side(DeviceSide &S)
 {
     (void)hipFree(S.packed); (void)hipFree(S.widx); (void)hipFree(S.wval); (void)hipFree(S.task_major);
-    (void)hipFree(S.inv_task); (void)hipFree(S.slice_width); (void)hipFree(S.seg_block); (void)hipFree(S.seg_slice0);
+    (void)hipFree(S.inv_task); (void)hipFree(S.slice_width); (void)hipFree(S.seg_block); (void)hipFree(S.segwave_ptr); (void)hipFree(S.segwave_slice);
     (void)hipFree(S.wg_seg0); (void)hipFree(S.inv_ptr); (void)hipFree(S.slice_off); (void)hipFree(S.part);
     S = DeviceSide();
 }
@@ -114,7 +117,8 @@ int upload_side(const Layout &L, int R, DeviceSide &S)
     if (int rc = dev_upload(&S.slice_width, L.slice_width)) return rc;
     if (int rc = dev_upload(&S.slice_off, L.slice_off)) return rc;
     if (int rc = dev_upload(&S.seg_block, L.seg_block)) return rc;
-    if (int rc = dev_upload(&S.seg_slice0, L.seg_slice0)) return rc;
+    if (int rc = dev_upload(&S.segwave_ptr, L.segwave_ptr)) return rc;
+    if (int rc = dev_upload(&S.segwave_slice, L.segwave_slice)) return rc;
     if (int rc = dev_upload(&S.wg_seg0, L.wg_seg0)) return rc;
     if (int rc = dev_upload(&S.inv_ptr, L.inv_ptr)) return rc;
     if (int rc = dev_upload(&S.inv_task, L.inv_task)) return rc;
@@ -127,7 +131,7 @@ SweepSide sweep_side_args(const vbnmf_engine *e, const DeviceSide &S, bool gene_
     SweepSide P;
     P.packed = S.packed; P.widx = S.widx; P.wval = S.wval;
     P.task_major = S.task_major; P.slice_width = S.slice_width; P.slice_off = S.slice_off;
-    P.seg_block = S.seg_block; P.seg_slice0 = S.seg_slice0; P.wg_seg0 = S.wg_seg0;
+    P.seg_block = S.seg_block; P.wg_seg0 = S.wg_seg0; P.segwave_ptr = S.segwave_ptr; P.segwave_slice = S.segwave_slice;
     P.F = gene_side ? e->lw : e->lh;
     P.llF = gene_side ? e->llw : e->llh;
     P.G = gene_side ? e->lh : e->lw;
@@ -135,6 +139,8 @@ SweepSide sweep_side_args(const vbnmf_engine *e, const DeviceSide &S, bool gene_
     P.n_minor = (int32_t)S.n_minor; P.block_width = S.block_width;
     P.logterm = gene_side ? 1 : 0;
     P.n_wg = S.n_wg;
+    P.logtab = e->logtab;
+    P.dbg = e->dbg ? e->dbg + (gene_side ? 0 : e->dbg_count / 2) : nullptr;
     return P;
 }
 
@@ -327,7 +333,7 @@ void vbnmf_engine_destroy(vbnmf_engine *e)
     (void)hipFree(e->lw); (void)hipFree(e->llw); (void)hipFree(e->ew); (void)hipFree(e->dw);
     (void)hipFree(e->lh); (void)hipFree(e->llh); (void)hipFree(e->eh); (void)hipFree(e->dh);
     (void)hipFree(e->epart); (void)hipFree(e->bpW); (void)hipFree(e->bpH);
-    (void)hipFree(e->red); (void)hipFree(e->d_out);
+    (void)hipFree(e->red); (void)hipFree(e->d_out); (void)hipFree(e->dbg); (void)hipFree(e->logtab);
     if (e->h_out) (void)hipHostFree(e->h_out);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
@@ -380,7 +386,12 @@ int vbnmf_engine_create_part(const vbnmf_matrix *X, int64_t cb, int64_t ce, int6
     }
     if (rc) return bail(rc);
     e->lgx = (cb == 0 && ce == X->M.m) ? X->lgx : sum_lgamma_x1(X->M, cb, ce);
-    e->lds_bytes = (size_t)std::max(e->A.block_width, e->B.block_width) * e->R * sizeof(double);
+    e->lds_bytes = kLdsTabBytes + (size_t)std::max(e->A.block_width, e->B.block_width) * lds_row_bytes(e->R);
+    {
+        std::vector<LogTabEntry> tab(kLogTabSize);
+        fill_log_table(tab.data());
+        if ((rc = dev_upload(&e->logtab, tab))) return bail(rc);
+    }
 
     const size_t nR = (size_t)e->n * e->R, mR = (size_t)e->m * e->R;
     const size_t bpn = (size_t)kUpdateBlocks * (e->R + 2);
@@ -399,6 +410,10 @@ int vbnmf_engine_create_part(const vbnmf_matrix *X, int64_t cb, int64_t ce, int6
         return bail(fail(VBNMF_ERR_HIP, "engine setup failed: %s", hipGetErrorString(he)));
     e->own_stream = true;
     std::memset(e->h_out, 0, 8 * sizeof(double));
+    if (getenv("VBNMF_DEBUG_TIMES")) {
+        e->dbg_count = 2 * (size_t)e->n_wg * (2 + 2 * (e->NT / 64));
+        if ((rc = dev_alloc(&e->dbg, e->dbg_count))) return bail(rc);
+    }
     if ((he = hipMemset(e->ew, 0, nR * sizeof(double))) != hipSuccess || (he = hipMemset(e->dw, 0, nR * sizeof(double))) != hipSuccess ||
         (he = hipMemset(e->dh, 0, mR * sizeof(double))) != hipSuccess || (he = hipMemset(e->bpW, 0, bpn * sizeof(double))) != hipSuccess ||
         (he = hipMemset(e->bpH, 0, bpn * sizeof(double))) != hipSuccess || (he = hipMemset(e->red, 0, (size_t)e->red_count * sizeof(double))) != hipSuccess)
@@ -601,6 +616,23 @@ int vbnmf_engine_layout_info(const vbnmf_engine *e, int64_t *nnz, int64_t *slots
     return VBNMF_OK;
 }
 
+// Diagnostic: per-workgroup / per-wave 100 MHz timestamps of the last sweep (engine created with
+// VBNMF_DEBUG_TIMES=1): out[side][wg][2 + 2*waves] = {wg start, wg end, (wave start, wave end)...}.
+int vbnmf_engine_debug_times(vbnmf_engine *e, unsigned long long *out, int64_t capacity, int32_t *n_wg, int32_t *waves)
+{
+    if (!e) return fail(VBNMF_ERR_BAD_ARG, "engine handle is NULL");
+    if (!e->dbg) return fail(VBNMF_ERR_STATE, "engine was not created with VBNMF_DEBUG_TIMES=1");
+    if (n_wg) *n_wg = e->n_wg;
+    if (waves) *waves = e->NT / 64;
+    if (out) {
+        if ((size_t)capacity < e->dbg_count) return fail(VBNMF_ERR_BAD_ARG, "buffer too small");
+        if (int rc = use_device(e)) return rc;
+        HIPCHECK(hipStreamSynchronize(e->stream));
+        HIPCHECK(hipMemcpy(out, e->dbg, e->dbg_count * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    }
+    return VBNMF_OK;
+}
+
 // ---------------------------------------------------------------- test hooks
 int vbnmf_test_special_host(int32_t kind, int64_t n, const double *x, double *y)
 {
@@ -611,6 +643,7 @@ int vbnmf_test_special_host(int32_t kind, int64_t n, const double *x, double *y)
             case 0: y[i] = dev_log(x[i]); break;
             case 1: dev_psi_lgamma(x[i], &psi, &lg); y[i] = psi; break;
             case 2: dev_psi_lgamma(x[i], &psi, &lg); y[i] = lg; break;
+            case 6: { static LogTabEntry tab[kLogTabSize]; static bool init = false; if (!init) { fill_log_table(tab); init = true; } y[i] = dev_log_tab(x[i], tab); break; }
             default: y[i] = dev_div(1.0, x[i]); break;
         }
     }
@@ -623,17 +656,21 @@ int vbnmf_test_special_device(int32_t kind, int64_t n, const double *x, double *
     if (int rc = check_device(0)) return rc;
     HIPCHECK(hipSetDevice(0));
     double *dx = nullptr, *dy = nullptr;
+    LogTabEntry *dt = nullptr;
+    std::vector<LogTabEntry> tab(kLogTabSize);
+    fill_log_table(tab.data());
     if (int rc = dev_alloc(&dx, (size_t)n)) return rc;
     if (int rc = dev_alloc(&dy, (size_t)n)) { (void)hipFree(dx); return rc; }
+    if (int rc = dev_upload(&dt, tab)) { (void)hipFree(dx); (void)hipFree(dy); return rc; }
     int rc = VBNMF_OK;
     hipError_t he = hipMemcpy(dx, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice);
     if (he == hipSuccess && n > 0) {
-        hipLaunchKernelGGL(k_test_special, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, kind, n, dx, dy);
+        hipLaunchKernelGGL(k_test_special, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, kind, n, dx, dy, dt);
         he = hipGetLastError();
     }
     if (he == hipSuccess) he = hipMemcpy(y, dy, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
     if (he != hipSuccess) rc = fail(VBNMF_ERR_HIP, "special-function test kernel failed: %s", hipGetErrorString(he));
-    (void)hipFree(dx); (void)hipFree(dy);
+    (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dt);
     return rc;
 }
 

@@ -251,7 +251,7 @@ LayoutParams default_layout_params(int64_t n_major, int64_t n_minor, int R, int 
     int lds_kb = env_int("VBNMF_LDS_KB", 160);
     if (lds_kb < 8) lds_kb = 8;
     if (lds_kb > 160) lds_kb = 160;
-    int64_t cmax = (int64_t)lds_kb * 1024 / ((int64_t)R * 8);
+    int64_t cmax = ((int64_t)lds_kb * 1024 - kLdsReserveBytes) / lds_row_bytes(R);
     cmax &= ~(int64_t)7;
     if (cmax > 65528) cmax = 65528;            // local minor index is 16 bits
     if (cmax < 8) cmax = 8;
@@ -266,13 +266,14 @@ LayoutParams default_layout_params(int64_t n_major, int64_t n_minor, int R, int 
     if (n_wg <= 0) n_wg = env_int("VBNMF_NWG", 256);
     if (n_wg < 1) n_wg = 1;
     lp.n_wg = n_wg;
+    lp.n_waves = sweep_threads(R) / kLanes;
     return lp;
 }
 
 int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const LayoutParams &lp, Layout &L)
 {
     if (cb < 0 || ce > X.m || cb >= ce) return fail(VBNMF_ERR_BAD_ARG, "column range [%lld, %lld) is outside the matrix", (long long)cb, (long long)ce);
-    if (lp.block_width <= 0 || lp.block_width > 65536 || lp.max_len <= 0 || lp.max_len % kWidthQuantum || lp.n_wg <= 0)
+    if (lp.block_width <= 0 || lp.block_width > 65536 || lp.max_len <= 0 || lp.max_len % kWidthQuantum || lp.n_wg <= 0 || lp.n_waves <= 0)
         return fail(VBNMF_ERR_BAD_ARG, "bad layout parameters");
 
     // major-compressed view of X[:, cb:ce)
@@ -295,6 +296,7 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
     L.block_width = lp.block_width;
     L.max_len = lp.max_len;
     L.n_wg = lp.n_wg;
+    L.n_waves = lp.n_waves;
     const int64_t nmaj = L.n_major;
     const int32_t C = L.block_width;
     const int32_t nblk = (int32_t)((L.n_minor + C - 1) / C);
@@ -396,32 +398,102 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
         });
     }
 
-    // persistent workgroups: contiguous slice ranges of equal cost; segments = runs of one block
+    // persistent workgroups.  Shares are block-aligned so a workgroup stages one block per side:
+    // whole workgroups are apportioned to blocks in proportion to block cost (largest remainder);
+    // a block's slices, sorted by width, are dealt to its workgroups in snake order (equal cost,
+    // same mix of long and short slices); inside a share the slices are bin-packed onto the waves,
+    // longest first to the least loaded wave.  With more blocks than workgroups, whole blocks are
+    // bin-packed onto workgroups instead.
     {
-        const double c0 = 8.0;                               // per-slice overhead in entry-equivalents
-        std::vector<double> pre(L.n_slices + 1, 0.0);
-        for (int64_t s = 0; s < L.n_slices; s++) pre[s + 1] = pre[s] + L.slice_width[s] + c0;
-        const double total = pre[L.n_slices];
+        const double c0 = 10.0;                              // per-slice overhead in entry-equivalents
+        auto cost = [&](int64_t s) { return (double)L.slice_width[s] + c0; };
+        std::vector<double> bcost(nblk, 0.0);
+        double total = 0.0;
+        for (int32_t blk = 0; blk < nblk; blk++) {
+            for (int64_t s = bslice0[blk]; s < bslice0[blk + 1]; s++) bcost[blk] += cost(s);
+            total += bcost[blk];
+        }
+        // shares[w] = list of (block, slices) segments of workgroup w
+        std::vector<std::vector<std::pair<int32_t, std::vector<int32_t>>>> shares(L.n_wg);
+        std::vector<int32_t> live;                            // blocks that have slices
+        for (int32_t blk = 0; blk < nblk; blk++) if (bslice0[blk + 1] > bslice0[blk]) live.push_back(blk);
+        if ((int64_t)live.size() <= L.n_wg && !live.empty()) {
+            std::vector<int> G(nblk, 0);
+            std::vector<std::pair<double, int32_t>> frac;
+            int used = 0;
+            for (int32_t blk : live) {
+                double quota = L.n_wg * bcost[blk] / total;
+                int g = std::max(1, (int)std::floor(quota));
+                g = (int)std::min<int64_t>(g, bslice0[blk + 1] - bslice0[blk]);
+                G[blk] = g; used += g;
+                frac.emplace_back(quota - g, blk);
+            }
+            std::stable_sort(frac.begin(), frac.end(), [](const std::pair<double, int32_t> &x, const std::pair<double, int32_t> &y) { return x.first > y.first; });
+            for (size_t q = 0; used < L.n_wg && !frac.empty(); q = (q + 1) % frac.size()) {   // hand out the spare workgroups
+                int32_t blk = frac[q].second;
+                if (G[blk] < bslice0[blk + 1] - bslice0[blk]) { G[blk]++; used++; }
+                else if (q + 1 == frac.size()) { bool any = false; for (auto &f : frac) any |= G[f.second] < bslice0[f.second + 1] - bslice0[f.second]; if (!any) break; }
+            }
+            while (used > L.n_wg) {                           // too many (each block needs at least one): shrink the most over-served
+                int32_t worst = -1;
+                for (int32_t blk : live) if (G[blk] > 1 && (worst < 0 || bcost[blk] / G[blk] < bcost[worst] / G[worst])) worst = blk;
+                if (worst < 0) break;
+                G[worst]--; used--;
+            }
+            int w = 0;
+            for (int32_t blk : live) {
+                const int g = G[blk];
+                const int64_t s0 = bslice0[blk], s1 = bslice0[blk + 1];
+                for (int j = 0; j < g; j++) shares[w + j].emplace_back(blk, std::vector<int32_t>());
+                for (int64_t i = s0; i < s1; i++) {            // slices are in descending width order: snake deal
+                    int64_t k = i - s0, round = k / g, pos = k % g;
+                    int j = (round & 1) ? (int)(g - 1 - pos) : (int)pos;
+                    shares[w + j].back().second.push_back((int32_t)i);
+                }
+                w += g;
+            }
+        } else {
+            std::vector<int32_t> ord(live);
+            std::stable_sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) { return bcost[x] > bcost[y]; });
+            std::vector<double> load(L.n_wg, 0.0);
+            for (int32_t blk : ord) {
+                int best = 0;
+                for (int w = 1; w < L.n_wg; w++) if (load[w] < load[best]) best = w;
+                shares[best].emplace_back(blk, std::vector<int32_t>());
+                for (int64_t i = bslice0[blk]; i < bslice0[blk + 1]; i++) shares[best].back().second.push_back((int32_t)i);
+                load[best] += bcost[blk];
+            }
+            for (auto &sh : shares)
+                std::stable_sort(sh.begin(), sh.end(), [](const std::pair<int32_t, std::vector<int32_t>> &x, const std::pair<int32_t, std::vector<int32_t>> &y) { return x.first < y.first; });
+        }
         L.wg_seg0.assign(L.n_wg + 1, 0);
         L.seg_block.clear();
-        L.seg_slice0.clear();
-        int64_t s = 0;
+        L.segwave_ptr.assign(1, 0);
+        L.segwave_slice.clear();
+        L.segwave_slice.reserve(L.n_slices);
+        std::vector<std::vector<int32_t>> lists(L.n_waves);
+        std::vector<double> load(L.n_waves);
         for (int w = 0; w < L.n_wg; w++) {
             L.wg_seg0[w] = (int32_t)L.seg_block.size();
-            const double lim = total * (w + 1) / L.n_wg;
-            int64_t e = s;
-            if (w == L.n_wg - 1) e = L.n_slices;
-            else while (e < L.n_slices && 0.5 * (pre[e] + pre[e + 1]) <= lim) e++;
-            while (s < e) {                                   // cut [s, e) at block changes
-                int64_t t = s;
-                while (t < e && L.slice_block[t] == L.slice_block[s]) t++;
-                L.seg_block.push_back(L.slice_block[s]);
-                L.seg_slice0.push_back((int32_t)s);
-                s = t;
+            for (auto &seg : shares[w]) {
+                std::vector<int32_t> &sl = seg.second;
+                std::stable_sort(sl.begin(), sl.end(), [&](int32_t x, int32_t y) { return L.slice_width[x] > L.slice_width[y]; });
+                for (auto &l : lists) l.clear();
+                std::fill(load.begin(), load.end(), 0.0);
+                for (int32_t id : sl) {
+                    int best = 0;
+                    for (int v = 1; v < L.n_waves; v++) if (load[v] < load[best]) best = v;
+                    lists[best].push_back(id);
+                    load[best] += cost(id);
+                }
+                L.seg_block.push_back(seg.first);
+                for (int v = 0; v < L.n_waves; v++) {
+                    L.segwave_slice.insert(L.segwave_slice.end(), lists[v].begin(), lists[v].end());
+                    L.segwave_ptr.push_back((int32_t)L.segwave_slice.size());
+                }
             }
         }
         L.wg_seg0[L.n_wg] = (int32_t)L.seg_block.size();
-        L.seg_slice0.push_back((int32_t)L.n_slices);
         L.n_segs = (int64_t)L.seg_block.size();
     }
 
@@ -432,20 +504,92 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
         return fail(VBNMF_ERR_OOM, "out of host memory building the tiled layout (%lld slots)", (long long)L.n_slots);
     }
 
-    // fill: slot(t, lane) = off + (t/4)*256 + lane*4 + t%4 ; padding slots stay {minor 0, value 0}
+    // fill: slot(t, lane) = off + (t/4)*256 + lane*4 + t%4 ; padding slots stay {minor 0, value 0}.
+    //
+    // The order of a task's entries is free (it only fixes the summation order), so it is chosen
+    // to keep the LDS gathers of the sweep conflict-free: a ds_read_b128 wave instruction is served
+    // in four fixed groups of 16 lanes, one LDS cycle per group when the 16 addresses fall in 16
+    // different 16-byte bank slots.  Rows of the staged factor are an odd number of slots long, so
+    // the slot of piece p of row `local` is (stride*local + p) mod 16: two lanes of a group collide
+    // exactly when their minors are congruent mod 16.  Step by step, each group therefore hands out
+    // distinct residues (local mod 16) to its lanes: residues in order of remaining demand, each to
+    // the lane with the fewest other residues left; a lane that finds all its residues taken
+    // doubles up on the least used one.
+    static const int kGroupOf[64] = {0,0,0,0,1,1,1,1,1,1,1,1,0,0,0,0,1,1,1,1,0,0,0,0,0,0,0,0,1,1,1,1,
+                                     2,2,2,2,3,3,3,3,3,3,3,3,2,2,2,2,3,3,3,3,2,2,2,2,2,2,2,2,3,3,3,3};
+    const bool schedule = env_int("VBNMF_NO_BANK_SCHEDULE", 0) == 0;
     parallel_for(L.n_slices, [&](int64_t b, int64_t e, int) {
+        std::vector<int64_t> order;                       // entry positions of one lane in step order
+        std::vector<int32_t> bucket[16][16];              // [lane in group][residue] -> stack of positions
         for (int64_t s = b; s < e; s++) {
             const int32_t m0 = L.slice_block[s] * C;
             const int64_t so = L.slice_off[s];
-            for (int lane = 0; lane < kLanes; lane++) {
-                size_t id = (size_t)s * kLanes + lane;
-                if (L.task_major[id] == kIdleLane) continue;
-                const int64_t q0 = task_pos[id];
-                for (int64_t t = 0; t < task_len[id]; t++) {
-                    int64_t slot = so + (t / kUnroll) * (kLanes * kUnroll) + lane * kUnroll + (t % kUnroll);
-                    uint32_t local = (uint32_t)(idx[q0 + t] - m0);
-                    if (L.wide) { L.wide_idx[slot] = local; L.wide_val[slot] = val[q0 + t]; }
-                    else L.packed[slot] = ((uint32_t)val[q0 + t] << 16) | local;
+            auto put = [&](int lane, int64_t t, int64_t q) {
+                int64_t slot = so + (t / kUnroll) * (kLanes * kUnroll) + lane * kUnroll + (t % kUnroll);
+                uint32_t local = (uint32_t)(idx[q] - m0);
+                if (L.wide) { L.wide_idx[slot] = local; L.wide_val[slot] = val[q]; }
+                else L.packed[slot] = ((uint32_t)val[q] << 16) | local;
+            };
+            if (!schedule) {
+                for (int lane = 0; lane < kLanes; lane++) {
+                    size_t id = (size_t)s * kLanes + lane;
+                    if (L.task_major[id] == kIdleLane) continue;
+                    for (int64_t t = 0; t < task_len[id]; t++) put(lane, t, task_pos[id] + t);
+                }
+                continue;
+            }
+            for (int g = 0; g < 4; g++) {
+                int lanes[16], nl = 0;
+                for (int lane = 0; lane < kLanes; lane++) if (kGroupOf[lane] == g) lanes[nl++] = lane;
+                int cnt[16][16] = {}, rem[16] = {}, step[16] = {}, dem[16] = {};
+                int T = 0;
+                for (int j = 0; j < 16; j++) {
+                    for (int r = 0; r < 16; r++) bucket[j][r].clear();
+                    size_t id = (size_t)s * kLanes + lanes[j];
+                    if (L.task_major[id] == kIdleLane) continue;
+                    const int64_t q0 = task_pos[id];
+                    for (int32_t t = task_len[id] - 1; t >= 0; t--) {      // reversed: stacks pop in ascending minor order
+                        int r = (idx[q0 + t] - m0) & 15;
+                        bucket[j][r].push_back(t);
+                        cnt[j][r]++; dem[r]++;
+                    }
+                    rem[j] = task_len[id];
+                    T = std::max(T, rem[j]);
+                }
+                for (int t = 0; t < T; t++) {
+                    int used[16] = {};
+                    bool assigned[16] = {};
+                    int ord[16];
+                    for (int r = 0; r < 16; r++) ord[r] = r;
+                    std::stable_sort(ord, ord + 16, [&](int x, int y) { return dem[x] > dem[y]; });
+                    auto take = [&](int j, int r) {
+                        size_t id = (size_t)s * kLanes + lanes[j];
+                        int32_t tt = bucket[j][r].back();
+                        bucket[j][r].pop_back();
+                        put(lanes[j], step[j]++, task_pos[id] + tt);
+                        assigned[j] = true; used[r]++; cnt[j][r]--; dem[r]--; rem[j]--;
+                    };
+                    for (int oi = 0; oi < 16; oi++) {
+                        const int r = ord[oi];
+                        if (dem[r] == 0) break;
+                        int best = -1, best_opt = 99, best_cnt = -1;
+                        for (int j = 0; j < 16; j++) {
+                            if (assigned[j] || rem[j] == 0 || cnt[j][r] == 0) continue;
+                            int nopt = 0;
+                            for (int r2 = 0; r2 < 16; r2++) nopt += cnt[j][r2] > 0;
+                            if (nopt < best_opt || (nopt == best_opt && cnt[j][r] > best_cnt)) { best = j; best_opt = nopt; best_cnt = cnt[j][r]; }
+                        }
+                        if (best >= 0) take(best, r);
+                    }
+                    for (int j = 0; j < 16; j++) {
+                        if (assigned[j] || rem[j] == 0) continue;
+                        int best = -1;
+                        for (int r = 0; r < 16; r++) {
+                            if (cnt[j][r] == 0) continue;
+                            if (best < 0 || used[r] < used[best] || (used[r] == used[best] && dem[r] > dem[best])) best = r;
+                        }
+                        take(j, best);
+                    }
                 }
             }
         }
@@ -567,10 +711,12 @@ int vbnmf_layout_build(const vbnmf_matrix *X, int64_t col_begin, int64_t col_end
     view->side = L.side; view->wide = L.wide ? 1 : 0;
     view->n_major = L.n_major; view->n_minor = L.n_minor;
     view->block_width = L.block_width; view->n_blocks = L.n_blocks; view->max_len = L.max_len; view->n_wg = L.n_wg;
+    view->n_waves = L.n_waves;
     view->n_tasks = L.n_tasks; view->n_slices = L.n_slices; view->n_slots = L.n_slots; view->n_segs = L.n_segs;
     view->task_major = L.task_major.data(); view->slice_width = L.slice_width.data();
     view->slice_off = L.slice_off.data(); view->slice_block = L.slice_block.data();
-    view->seg_block = L.seg_block.data(); view->seg_slice0 = L.seg_slice0.data(); view->wg_seg0 = L.wg_seg0.data();
+    view->seg_block = L.seg_block.data(); view->wg_seg0 = L.wg_seg0.data();
+    view->segwave_ptr = L.segwave_ptr.data(); view->segwave_slice = L.segwave_slice.data();
     view->inv_ptr = L.inv_ptr.data(); view->inv_task = L.inv_task.data();
     view->packed = L.wide ? nullptr : L.packed.data();
     view->wide_idx = L.wide ? L.wide_idx.data() : nullptr;

@@ -42,8 +42,9 @@ struct SweepSide {
     const int32_t *slice_width;    // [n_slices]
     const int64_t *slice_off;      // [n_slices]
     const int32_t *seg_block;      // [n_segs]
-    const int32_t *seg_slice0;     // [n_segs + 1]
     const int32_t *wg_seg0;        // [n_wg + 1]
+    const int32_t *segwave_ptr;    // [n_segs * waves + 1]
+    const int32_t *segwave_slice;  // [n_slices] slices of (segment, wave) in processing order
     const double *F;               // [n_major][R]  factor owned by the lanes
     const double *llF;             // [n_major][R]  F * log F
     const double *G;               // [n_minor][R]  factor gathered through LDS
@@ -53,6 +54,8 @@ struct SweepSide {
     int32_t block_width;
     int32_t logterm;               // this side also accumulates sum x*log(wth)
     int32_t n_wg;
+    const LogTabEntry *logtab;     // [128] ln table (staged at the front of LDS)
+    unsigned long long *dbg;       // diagnostic: [n_wg][2 + 2*waves] 100 MHz timestamps, or null
 };
 
 template <int R>
@@ -66,6 +69,9 @@ struct SweepRegs {
 template <int R>
 __device__ __forceinline__ void lds_row(const double2 *__restrict__ ldsG, uint32_t byte_off, double2 (&gv)[R / 2])
 {
+#if defined(VBNMF_ABLATE_LDS_BCAST)
+    byte_off = 0;                                          // every lane reads row 0: pure broadcast, no conflicts
+#endif
     const double2 *g = reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(ldsG) + byte_off);
 #pragma unroll
     for (int kk = 0; kk < R / 2; kk++) gv[kk] = g[kk];
@@ -85,12 +91,15 @@ __device__ __forceinline__ void pin(Group4 &g)
 {
     asm volatile("" : "+v"(g.o0), "+v"(g.o1), "+v"(g.o2), "+v"(g.o3), "+v"(g.c0), "+v"(g.c1), "+v"(g.c2), "+v"(g.c3));
 }
+// LDS image of the sweep: [0, kLdsTabBytes) the ln table, then the staged factor block.
+constexpr uint32_t kLdsTabBytes = kLogTabSize * sizeof(LogTabEntry);
 template <int R>
 __device__ __forceinline__ Group4 unpack4(const uint4 e)
 {
+    constexpr uint32_t kRow = ((R / 2) | 1) * 16;          // LDS row stride: odd number of 16-byte slots
     Group4 g;
-    g.o0 = (e.x & 0xFFFFu) * (R * 8); g.o1 = (e.y & 0xFFFFu) * (R * 8);
-    g.o2 = (e.z & 0xFFFFu) * (R * 8); g.o3 = (e.w & 0xFFFFu) * (R * 8);
+    g.o0 = (e.x & 0xFFFFu) * kRow + kLdsTabBytes; g.o1 = (e.y & 0xFFFFu) * kRow + kLdsTabBytes;
+    g.o2 = (e.z & 0xFFFFu) * kRow + kLdsTabBytes; g.o3 = (e.w & 0xFFFFu) * kRow + kLdsTabBytes;
     g.c0 = e.x >> 16; g.c1 = e.y >> 16; g.c2 = e.z >> 16; g.c3 = e.w >> 16;
     return g;
 }
@@ -100,21 +109,32 @@ __device__ __forceinline__ Group4 unpack4(const uint4 e)
 // there is finite and non-zero.  It can only fail to be when a whole factor row is 0 or
 // non-finite, and then the reference's dense X/wth (src/vbnmf_update.cpp:34) is NaN as well.
 template <int R>
-__device__ __forceinline__ void sweep_entry(SweepRegs<R> &S, const double2 (&gv)[R / 2], double x, bool logterm)
+__device__ __forceinline__ void sweep_entry(SweepRegs<R> &S, const double2 *__restrict__ ldsG, const double2 (&gv)[R / 2],
+                                            double x, bool logterm)
 {
-    double wth = 0.0;
+    // two interleaved partial sums (even / odd k): half the dependent-chain length
+    double w0 = S.F[0] * gv[0].x, w1 = S.F[1] * gv[0].y;
 #pragma unroll
-    for (int kk = 0; kk < R / 2; kk++) {
-        wth = fma(S.F[2 * kk], gv[kk].x, wth);
-        wth = fma(S.F[2 * kk + 1], gv[kk].y, wth);
+    for (int kk = 1; kk < R / 2; kk++) {
+        w0 = fma(S.F[2 * kk], gv[kk].x, w0);
+        w1 = fma(S.F[2 * kk + 1], gv[kk].y, w1);
     }
+    const double wth = w0 + w1;
+#if defined(VBNMF_ABLATE_NODIV)
+    const double q = x * wth;
+#else
     const double q = dev_div(x, wth);
+#endif
 #pragma unroll
     for (int kk = 0; kk < R / 2; kk++) {
         S.acc[2 * kk] = fma(q, gv[kk].x, S.acc[2 * kk]);
         S.acc[2 * kk + 1] = fma(q, gv[kk].y, S.acc[2 * kk + 1]);
     }
-    if (logterm) S.lsum = fma(x, dev_log(wth), S.lsum);
+#if defined(VBNMF_ABLATE_NOLOG)
+    if (logterm) S.lsum = fma(x, wth, S.lsum);
+#else
+    if (logterm) S.lsum = fma(x, dev_log_tab(wth, reinterpret_cast<const LogTabEntry *>(ldsG)), S.lsum);
+#endif
 }
 
 template <int R, bool WIDE, bool LOGTERM, int NT>
@@ -125,6 +145,8 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
     const int nwg = S.n_wg;
     const int wg = (nwg % 8 == 0) ? (int)(blockIdx.x % 8) * (nwg / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
     const int seg0 = S.wg_seg0[wg], seg1 = S.wg_seg0[wg + 1];
+    if (S.dbg && lane == 0) S.dbg[(size_t)wg * (2 + 2 * (NT / 64)) + 2 + 2 * wave] = __builtin_amdgcn_s_memrealtime();
+    if (S.dbg && threadIdx.x == 0) S.dbg[(size_t)wg * (2 + 2 * (NT / 64))] = __builtin_amdgcn_s_memrealtime();
     double ev_wave = 0.0;                                  // this wave's evidence contributions, in slice order
     for (int seg = seg0; seg < seg1; seg++) {
         const int blk = S.seg_block[seg];
@@ -132,13 +154,20 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
         const int cw = min(S.block_width, S.n_minor - m0);
         __syncthreads();                                   // readers of the previous block are done
         {
+            constexpr int kSlots = (R / 2) | 1;            // LDS row stride in 16-byte slots (odd)
             const double2 *G2 = reinterpret_cast<const double2 *>(S.G + (size_t)m0 * R);
             const int cnt = cw * (R / 2);
-            for (int t = threadIdx.x; t < cnt; t += NT) ldsG[t] = G2[t];
+            double2 *rows = ldsG + kLdsTabBytes / sizeof(double2);
+            for (int t = threadIdx.x; t < cnt; t += NT) {
+                const int row = t / (R / 2), kk = t - row * (R / 2);
+                rows[row * kSlots + kk] = G2[t];
+            }
+            if (threadIdx.x < kLogTabSize) ldsG[threadIdx.x] = reinterpret_cast<const double2 *>(S.logtab)[threadIdx.x];
         }
         __syncthreads();
-        const int s0 = S.seg_slice0[seg], s1 = S.seg_slice0[seg + 1];
-        for (int s = s0 + wave; s < s1; s += NT / 64) {
+        const int i0 = S.segwave_ptr[seg * (NT / 64) + wave], i1 = S.segwave_ptr[seg * (NT / 64) + wave + 1];
+        for (int i = i0; i < i1; i++) {
+            const int s = S.segwave_slice[i];
             const uint32_t M = S.task_major[(size_t)s * 64 + lane];
             const int ng = S.slice_width[s] >> 2;
             const int64_t off = S.slice_off[s];
@@ -163,44 +192,48 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
                 const uint4 *E = reinterpret_cast<const uint4 *>(S.packed + off) + lane;
                 Group4 a = unpack4<R>(E[0]), b = unpack4<R>(E[64]);
                 lds_row<R>(ldsG, a.o0, g0);
+                // FENCE keeps the machine scheduler from sinking a row's LDS reads down to their first
+                // use: the reads of entry j+1 stay in front of the arithmetic of entry j, which hides them.
+#define VBNMF_FENCE() __builtin_amdgcn_sched_barrier(0)
                 for (int p = 0; p < np; p++) {
                     const int pn = min(p + 1, np - 1);                    // last trip re-reads itself
                     const uint4 ec = E[(size_t)pn * 128], ed = E[(size_t)pn * 128 + 64];
-                    lds_row<R>(ldsG, a.o1, g1);
-                    sweep_entry<R>(T, g0, (double)a.c0, LOGTERM);
-                    lds_row<R>(ldsG, a.o2, g0);
-                    sweep_entry<R>(T, g1, (double)a.c1, LOGTERM);
-                    lds_row<R>(ldsG, a.o3, g1);
-                    sweep_entry<R>(T, g0, (double)a.c2, LOGTERM);
-                    lds_row<R>(ldsG, b.o0, g0);
-                    sweep_entry<R>(T, g1, (double)a.c3, LOGTERM);
-                    lds_row<R>(ldsG, b.o1, g1);
-                    sweep_entry<R>(T, g0, (double)b.c0, LOGTERM);
-                    lds_row<R>(ldsG, b.o2, g0);
-                    sweep_entry<R>(T, g1, (double)b.c1, LOGTERM);
-                    lds_row<R>(ldsG, b.o3, g1);
-                    sweep_entry<R>(T, g0, (double)b.c2, LOGTERM);
+                    lds_row<R>(ldsG, a.o1, g1); VBNMF_FENCE();
+                    sweep_entry<R>(T, ldsG, g0, (double)a.c0, LOGTERM); VBNMF_FENCE();
+                    lds_row<R>(ldsG, a.o2, g0); VBNMF_FENCE();
+                    sweep_entry<R>(T, ldsG, g1, (double)a.c1, LOGTERM); VBNMF_FENCE();
+                    lds_row<R>(ldsG, a.o3, g1); VBNMF_FENCE();
+                    sweep_entry<R>(T, ldsG, g0, (double)a.c2, LOGTERM); VBNMF_FENCE();
+                    lds_row<R>(ldsG, b.o0, g0); VBNMF_FENCE();
+                    sweep_entry<R>(T, ldsG, g1, (double)a.c3, LOGTERM); VBNMF_FENCE();
+                    lds_row<R>(ldsG, b.o1, g1); VBNMF_FENCE();
+                    sweep_entry<R>(T, ldsG, g0, (double)b.c0, LOGTERM); VBNMF_FENCE();
+                    lds_row<R>(ldsG, b.o2, g0); VBNMF_FENCE();
+                    sweep_entry<R>(T, ldsG, g1, (double)b.c1, LOGTERM); VBNMF_FENCE();
+                    lds_row<R>(ldsG, b.o3, g1); VBNMF_FENCE();
+                    sweep_entry<R>(T, ldsG, g0, (double)b.c2, LOGTERM); VBNMF_FENCE();
                     a = unpack4<R>(ec);
                     pin(a);
-                    lds_row<R>(ldsG, a.o0, g0);
-                    sweep_entry<R>(T, g1, (double)b.c3, LOGTERM);
+                    lds_row<R>(ldsG, a.o0, g0); VBNMF_FENCE();
+                    sweep_entry<R>(T, ldsG, g1, (double)b.c3, LOGTERM); VBNMF_FENCE();
                     b = unpack4<R>(ed);
                     pin(b);
                 }
+#undef VBNMF_FENCE
             } else {
                 const uint4 *E = reinterpret_cast<const uint4 *>(S.widx + off) + lane;
                 const double2 *V = reinterpret_cast<const double2 *>(S.wval + off) + lane * 2;
                 for (int g = 0; g < ng; g++) {
                     const uint4 c = E[(size_t)g * 64];
                     const double2 v0 = V[(size_t)g * 128], v1 = V[(size_t)g * 128 + 1];
-                    lds_row<R>(ldsG, c.x * (R * 8), g0);
-                    lds_row<R>(ldsG, c.y * (R * 8), g1);
-                    sweep_entry<R>(T, g0, v0.x, LOGTERM);
-                    lds_row<R>(ldsG, c.z * (R * 8), g0);
-                    sweep_entry<R>(T, g1, v0.y, LOGTERM);
-                    lds_row<R>(ldsG, c.w * (R * 8), g1);
-                    sweep_entry<R>(T, g0, v1.x, LOGTERM);
-                    sweep_entry<R>(T, g1, v1.y, LOGTERM);
+                    lds_row<R>(ldsG, c.x * (((R / 2) | 1) * 16) + kLdsTabBytes, g0);
+                    lds_row<R>(ldsG, c.y * (((R / 2) | 1) * 16) + kLdsTabBytes, g1);
+                    sweep_entry<R>(T, ldsG, g0, v0.x, LOGTERM);
+                    lds_row<R>(ldsG, c.z * (((R / 2) | 1) * 16) + kLdsTabBytes, g0);
+                    sweep_entry<R>(T, ldsG, g1, v0.y, LOGTERM);
+                    lds_row<R>(ldsG, c.w * (((R / 2) | 1) * 16) + kLdsTabBytes, g1);
+                    sweep_entry<R>(T, ldsG, g0, v1.x, LOGTERM);
+                    sweep_entry<R>(T, ldsG, g1, v1.y, LOGTERM);
                 }
             }
 
@@ -226,6 +259,7 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
             ev_wave += ev;                                 // meaningful in lane 0
         }
     }
+    if (S.dbg && lane == 0) S.dbg[(size_t)wg * (2 + 2 * (NT / 64)) + 3 + 2 * wave] = __builtin_amdgcn_s_memrealtime();
     // one evidence partial per workgroup: the waves' sums added in wave order
     __syncthreads();                                       // all LDS reads of the last block are done
     double *sm = reinterpret_cast<double *>(ldsG);
@@ -235,6 +269,7 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
         double t = 0.0;
         for (int w = 0; w < NT / 64; w++) t += sm[w];
         S.epart[wg] = t;
+        if (S.dbg) S.dbg[(size_t)wg * (2 + 2 * (NT / 64)) + 1] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
@@ -480,7 +515,8 @@ __global__ __launch_bounds__(1024) void k_final(const double *__restrict__ bpW, 
 }
 
 // Device-side evaluation of the special functions, for tests (tests/test_gpu_special.py).
-__global__ void k_test_special(int kind, int64_t n, const double *__restrict__ x, double *__restrict__ y)
+__global__ void k_test_special(int kind, int64_t n, const double *__restrict__ x, double *__restrict__ y,
+                               const LogTabEntry *__restrict__ tab)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -489,7 +525,10 @@ __global__ void k_test_special(int kind, int64_t n, const double *__restrict__ x
         case 0: y[i] = dev_log(x[i]); break;
         case 1: dev_psi_lgamma(x[i], &psi, &lg); y[i] = psi; break;
         case 2: dev_psi_lgamma(x[i], &psi, &lg); y[i] = lg; break;
-        default: y[i] = dev_div(1.0, x[i]); break;
+        case 3: y[i] = dev_div(1.0, x[i]); break;
+        case 4: y[i] = sp_rcp_seed(x[i]); break;             // raw v_rcp_f64
+        case 5: y[i] = (double)__builtin_amdgcn_rcpf((float)x[i]); break;   // raw v_rcp_f32
+        default: y[i] = dev_log_tab(x[i], tab); break;
     }
 }
 

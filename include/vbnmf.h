@@ -144,6 +144,11 @@ int vbnmf_engine_set_stream(vbnmf_engine *e, void *stream);
 int vbnmf_engine_timing_enable(vbnmf_engine *e, int32_t on);
 int vbnmf_engine_timing_get(vbnmf_engine *e, double *sweep_ms, int64_t *sweep_launches);
 
+/* Diagnostic (engine created with env VBNMF_DEBUG_TIMES=1): 100 MHz device timestamps of the last
+ * sweep, out[side][wg][2 + 2*waves] = {workgroup start, end, then (start, end) per wave}. */
+int vbnmf_engine_debug_times(vbnmf_engine *e, unsigned long long *out, int64_t capacity,
+                             int32_t *n_wg, int32_t *waves);
+
 /* Layout facts for roofline accounting / tests (any pointer may be NULL):
  * padded entry slots and bytes the two sweeps stream per step, task counts. */
 int vbnmf_engine_layout_info(const vbnmf_engine *e, int64_t *nnz, int64_t *slots_gene_side,
@@ -182,18 +187,20 @@ typedef struct {
     int32_t block_width;           /* minors per LDS block */
     int32_t n_blocks;              /* ceil(n_minor / block_width) */
     int32_t max_len;               /* longest task (entries per lane) */
-    int32_t n_wg;                  /* persistent workgroups the slice list is cut for */
+    int32_t n_wg;                  /* persistent workgroups the work list is cut for */
+    int32_t n_waves;               /* waves per workgroup the slices of a segment are packed onto */
     int64_t n_tasks, n_slices;     /* task = run of one major's entries in one block; slice = 64 tasks */
     int64_t n_slots;               /* padded entry slots (all slices) */
-    int64_t n_segs;                /* segment = run of slices of one block in one workgroup's range */
+    int64_t n_segs;                /* segment = the slices of one block in one workgroup's share */
     const uint32_t *task_major;    /* [n_slices*64] major of task slice*64+lane, 0xFFFFFFFF = idle lane */
     const int32_t *slice_width;    /* [n_slices] entries per lane (multiple of 8) */
     const int64_t *slice_off;      /* [n_slices] first slot of the slice; slot(t, lane) =
                                       off + (t/4)*256 + lane*4 + t%4 */
     const int32_t *slice_block;    /* [n_slices] minor block */
     const int32_t *seg_block;      /* [n_segs] */
-    const int32_t *seg_slice0;     /* [n_segs+1] */
-    const int32_t *wg_seg0;        /* [n_wg+1] */
+    const int32_t *wg_seg0;        /* [n_wg+1] segments of each workgroup */
+    const int32_t *segwave_ptr;    /* [n_segs*n_waves+1] slices of (segment, wave) ... */
+    const int32_t *segwave_slice;  /* [n_slices]         ... in processing order */
     const int32_t *inv_ptr;        /* [n_major+1] tasks of each major ... */
     const uint32_t *inv_task;      /* [n_tasks]   ... in the order their partials are summed */
     const uint32_t *packed;        /* [n_slots] (count << 16) | local minor    (wide == 0) */
@@ -209,7 +216,8 @@ void vbnmf_layout_destroy(vbnmf_layout *L);
  * Test hooks: the library's own fp64 ln / digamma / lnGamma (which stand in for libm's log
  * and GSL's gsl_sf_psi / gsl_sf_lngamma, reference src/vbnmf_update.cpp:59,63,73,81-89),
  * evaluated on the host build and on the device, so tests can check them against mpmath.
- * kind: 0 = ln(x), 1 = psi(x), 2 = lnGamma(x), 3 = 1/x.
+ * kind: 0 = ln(x), 1 = psi(x), 2 = lnGamma(x), 3 = 1/x, 4/5 = raw hardware reciprocal seeds
+ * (device only), 6 = the sweep's table-driven ln(x).
  * --------------------------------------------------------------------------------- */
 int vbnmf_test_special_host(int32_t kind, int64_t n, const double *x, double *y);
 int vbnmf_test_special_device(int32_t kind, int64_t n, const double *x, double *y);

@@ -21,7 +21,8 @@ def test_layout_roundtrip_packed(n, m, r, lam):
         assert v["wide"] == 0
         A = reconstruct(v)
         assert np.array_equal(A, X if side == 0 else X.T)
-        assert v["block_width"] * 8 * ((r + 1) // 2 * 2) <= 160 * 1024
+        R = (r + 1) // 2 * 2
+        assert v["block_width"] * (((R // 2) | 1) * 16) <= 160 * 1024
         assert v["n_slots"] >= M.nnz
 
 

@@ -38,6 +38,11 @@ def check_all(device):
     near1 = np.abs(xs - 1) < 0.3
     assert np.max(err[~near1]) < 4e-16, np.max(err[~near1])
     assert np.max(np.abs(got - ref)[near1]) < 1.2e-16, np.max(np.abs(got - ref)[near1])
+    # the sweep's table-driven ln: same bounds
+    got = evaluate(6, xs, device)
+    err = np.abs(got - ref) / np.maximum(np.abs(ref), 1e-300)
+    assert np.max(err[~near1]) < 6e-16, np.max(err[~near1])
+    assert np.max(np.abs(got - ref)[near1]) < 1.5e-16, np.max(np.abs(got - ref)[near1])
     # digamma: absolute error scaled by max(1, |psi|)  (only exp(psi) is consumed, src/vbnmf_update.cpp:59,63)
     got = evaluate(1, xs, device)
     ref = np.array([float(mpmath.digamma(mpmath.mpf(float(x)))) for x in xs])
