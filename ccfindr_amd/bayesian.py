@@ -194,72 +194,97 @@ class VBResult:
     nsteps: list = field(default_factory=list)     # iterations used by the selected run (not in the reference)
 
 
-def _bundle_rng(bundle, irun):
+def _bundle_rng(bundle, irun, rank):
+    """One independent stream per (run, rank): results do not depend on which process runs the task."""
     seed = bundle.get("seed")
-    return np.random.default_rng(None if seed is None else [int(seed), int(irun)])
+    return np.random.default_rng(None if seed is None else [int(seed), int(irun), int(rank)])
 
 
-def vb_iterate(irun, bundle):
-    """One run over all ranks; reference R/bayesian.R:303-390 with the engine as the update."""
+def _make_engine(bundle, rank):
+    factory = bundle.get("engine_factory")
+    if factory is not None:
+        return factory(bundle["mat"], rank)
+    return VBEngine(bundle["mat"], rank, device=bundle.get("device", 0))
+
+
+def vb_run_rank(irun, rank, bundle):
+    """One factorisation (one run, one rank): the body of the rank loop, reference R/bayesian.R:318-384,
+    with the engine as the update.  Returns the per-rank record vb_iterate stores."""
     X = bundle["mat"]
     nrow, ncol = X.shape
-    ranks = list(bundle["ranks"])
-    nrank = len(ranks)
-    rdat = [-math.inf] * nrank
-    wdat, hdat, dwdat, dhdat, hyperp, nsteps = {}, {}, {}, {}, {}, {}
-    nunif = [0] * nrank
     verbose = bundle["verbose"]
-    if verbose >= 2 and bundle["nrun"] > 1:
-        print(f"Run {irun}")
+    if rank > min(nrow, ncol):
+        raise ValueError("Rank exceeded min(nrow,ncol)")                         # :319-320
     ga, gb = np.atleast_1d(bundle["gamma_a"]), np.atleast_1d(bundle["gamma_b"])
-    rng = _bundle_rng(bundle, irun)
-    for irank in range(nrank):
-        rank = int(ranks[irank])
-        if rank > min(nrow, ncol):
-            raise ValueError("Rank exceeded min(nrow,ncol)")                     # :319-320
-        hyper = {"aw": float(ga[0]), "ah": float(ga[-1]), "bw": float(gb[0]), "bh": float(gb[-1])}   # :321-326
-        wh0 = vb_init(nrow, ncol, bundle.get("raw"), rank, hyper=hyper, initializer=bundle["initializer"], rng=rng)
-        eng = VBEngine(X, rank, device=bundle.get("device", 0))
-        try:
-            eng.set_state(wh0["lw"], wh0["lh"], wh0["eh"])
-            lk0 = 0.0
-            it = 0
-            for it in range(1, bundle["Itmax"] + 1):                             # :337
-                lkh, stats = eng.step(hyper, bundle["fudge"])                    # :339
-                if it > bundle["hyper_update_n0"] and it % bundle["hyper_update_dn"] == 0:   # :342
-                    hyper = hyper_update(bundle["hyper_update"], stats, hyper, Niter=100, Tol=1e-3)
-                if math.isnan(lkh):                                              # :345
+    hyper = {"aw": float(ga[0]), "ah": float(ga[-1]), "bw": float(gb[0]), "bh": float(gb[-1])}   # :321-326
+    rng = _bundle_rng(bundle, irun, rank)
+    wh0 = vb_init(nrow, ncol, bundle.get("raw"), rank, hyper=hyper, initializer=bundle["initializer"], rng=rng)
+    eng = _make_engine(bundle, rank)
+    try:
+        eng.set_state(wh0["lw"], wh0["lh"], wh0["eh"])
+        lk0 = 0.0
+        it = 0
+        for it in range(1, bundle["Itmax"] + 1):                                 # :337
+            lkh, stats = eng.step(hyper, bundle["fudge"])                        # :339
+            if it > bundle["hyper_update_n0"] and it % bundle["hyper_update_dn"] == 0:   # :342
+                hyper = hyper_update(bundle["hyper_update"], stats, hyper, Niter=100, Tol=1e-3)
+            if math.isnan(lkh):                                                  # :345
+                break
+            if it > 1 and it > bundle["hyper_update_n0"]:                        # :346-347
+                if lkh >= lk0 and abs(1 - lkh / lk0) < bundle["Tol"]:
                     break
-                if it > 1 and it > bundle["hyper_update_n0"]:                    # :346-347
-                    if lkh >= lk0 and abs(1 - lkh / lk0) < bundle["Tol"]:
-                        break
-                lk0 = lkh                                                        # :348
-                if verbose >= 3:
-                    print(f"{it}, log(evidence) = {lk0}, aw = {hyper['aw']}, bw = {hyper['bw']}, "
-                          f"ah = {hyper['ah']}, bh = {hyper['bh']}")
-            wh = eng.get_state(("ew", "eh", "dw", "dh"))
-        finally:
-            eng.close()
-        if verbose >= 2:
-            print(f"Rank = {rank}: Nsteps ={it}, log(evidence) ={lk0}, hyper = ({hyper['aw']},{hyper['bw']},"
-                  f"{hyper['ah']},{hyper['bh']})")
-        ew = wh["ew"]
-        contains_unif = np.abs(ew.max(axis=0) - ew.min(axis=0)) < bundle["Tol"]  # :368-369
-        if contains_unif.sum() > 0:
-            cols = ",".join(str(c + 1) for c in np.nonzero(contains_unif)[0])
-            warnings.warn(f"Rank {rank} row/column {cols} constant.")
-            if bundle["unif_stop"]:
+            lk0 = lkh                                                            # :348
+            if verbose >= 3:
+                print(f"{it}, log(evidence) = {lk0}, aw = {hyper['aw']}, bw = {hyper['bw']}, "
+                      f"ah = {hyper['ah']}, bh = {hyper['bh']}")
+        wh = eng.get_state(("ew", "eh", "dw", "dh"))
+    finally:
+        eng.close()
+    if verbose >= 2:
+        print(f"Rank = {rank}: Nsteps ={it}, log(evidence) ={lk0}, hyper = ({hyper['aw']},{hyper['bw']},"
+              f"{hyper['ah']},{hyper['bh']})")
+    ew = wh["ew"]
+    contains_unif = np.abs(ew.max(axis=0) - ew.min(axis=0)) < bundle["Tol"]      # :368-369
+    return {"rank": rank, "lk0": lk0, "ew": wh["ew"], "eh": wh["eh"], "sdw": np.sqrt(wh["dw"]), "sdh": np.sqrt(wh["dh"]),  # :382-383
+            "hyper": hyper, "nsteps": it, "unif": [int(c) + 1 for c in np.nonzero(contains_unif)[0]]}
+
+
+def assemble_run(records, ranks, unif_stop):
+    """The bookkeeping of one run over its rank records (reference R/bayesian.R:309-311, 368-388):
+    a rank with a constant basis column warns; with unif.stop it ends the rank scan there."""
+    nrank = len(ranks)
+    out = {"rdat": [-math.inf] * nrank, "wdat": {}, "hdat": {}, "hyperp": {}, "nunif": [0] * nrank,
+           "dwdat": {}, "dhdat": {}, "nsteps": {}}
+    for irank, rank in enumerate(ranks):
+        rec = records.get(rank)
+        if rec is None:
+            break
+        if rec["unif"]:
+            warnings.warn(f"Rank {rank} row/column {','.join(str(c) for c in rec['unif'])} constant.")
+            if unif_stop:
                 warnings.warn(f"Rank scan stopped for rank >= {rank}")
                 if irank == 0:
                     raise RuntimeError("Rerun with lower ranks")                 # :375
                 break
-        rdat[irank] = lk0                                                        # :379
-        wdat[irank] = wh["ew"]; hdat[irank] = wh["eh"]
-        dwdat[irank] = np.sqrt(wh["dw"]); dhdat[irank] = np.sqrt(wh["dh"])       # :382-383
-        hyperp[irank] = hyper
-        nsteps[irank] = it
-    return {"rdat": rdat, "wdat": wdat, "hdat": hdat, "hyperp": hyperp, "nunif": nunif,
-            "dwdat": dwdat, "dhdat": dhdat, "nsteps": nsteps}
+        out["rdat"][irank] = rec["lk0"]                                          # :379
+        out["wdat"][irank] = rec["ew"]; out["hdat"][irank] = rec["eh"]
+        out["dwdat"][irank] = rec["sdw"]; out["dhdat"][irank] = rec["sdh"]
+        out["hyperp"][irank] = rec["hyper"]; out["nsteps"][irank] = rec["nsteps"]
+    return out
+
+
+def vb_iterate(irun, bundle):
+    """One run over all ranks; reference R/bayesian.R:303-390."""
+    ranks = [int(r) for r in bundle["ranks"]]
+    if bundle["verbose"] >= 2 and bundle["nrun"] > 1:
+        print(f"Run {irun}")
+    records = {}
+    for rank in ranks:
+        rec = vb_run_rank(irun, rank, bundle)
+        records[rank] = rec
+        if rec["unif"] and bundle["unif_stop"]:
+            break                                                                # :373-377
+    return assemble_run(records, ranks, bundle["unif_stop"])
 
 
 def select_best(vb, ranks):
@@ -287,7 +312,7 @@ def select_best(vb, ranks):
 
 
 def make_bundle(mat, ranks, nrun, verbose, initializer, Itmax, hyper_update, gamma_a, gamma_b, Tol,
-                hyper_update_n0, hyper_update_dn, fudge, unif_stop, seed, device):
+                hyper_update_n0, hyper_update_dn, fudge, unif_stop, seed, device, engine_factory=None):
     """Argument handling and guards of reference R/bayesian.R:238-259."""
     if fudge is None:
         fudge = EPS                                                              # :238
@@ -304,25 +329,27 @@ def make_bundle(mat, ranks, nrun, verbose, initializer, Itmax, hyper_update, gam
             "gamma_a": gamma_a, "gamma_b": gamma_b, "initializer": initializer, "Itmax": Itmax, "fudge": fudge,
             "hyper_update": list(hyper_update), "hyper_update_n0": hyper_update_n0,
             "hyper_update_dn": hyper_update_dn, "Tol": Tol, "unif_stop": unif_stop, "nrun": nrun,
-            "seed": seed, "device": device}
+            "seed": seed, "device": device, "engine_factory": engine_factory}
 
 
 def vb_factorize(mat, ranks=2, nrun=1, verbose=2, progress_bar=True, initializer="random", Itmax=10000,
                  hyper_update=(True, True, True, True), gamma_a=1, gamma_b=1, Tol=1e-5,
                  hyper_update_n0=10, hyper_update_dn=1, connectivity=False, fudge=None, ncores=1,
-                 useC=True, unif_stop=True, seed=None, device=0):
+                 useC=True, unif_stop=True, seed=None, device=0, engine_factory=None):
     """Bayesian NMF of a count matrix on the MI355X engine; reference R/bayesian.R:229-301.
 
     ``mat`` is the genes x cells count matrix (dense, scipy sparse, or ``CountMatrix``).
     ``connectivity`` (reference default TRUE) is post-processing outside this path and is
     not computed; ``ncores`` / Rmpi is replaced by ``ccfindr_amd.parallel``; ``useC`` selects
     nothing (the native engine is the only backend); ``progress_bar`` is unused, as in the
-    reference.  ``seed`` seeds the numpy Generator of the ``random`` initialiser.
+    reference.  ``seed`` seeds the numpy Generator of the ``random`` initialiser (one stream
+    per (run, rank)).  ``engine_factory(mat, rank)`` replaces the engine constructor (used by
+    ``ccfindr_amd.parallel`` for cell-partitioned engines, and by the CPU tests of this loop).
     """
     del progress_bar, useC, ncores
     if connectivity:
         warnings.warn("connectivity/dispersion are outside the VB update path and are not computed")
     bundle = make_bundle(mat, ranks, nrun, verbose, initializer, Itmax, hyper_update, gamma_a, gamma_b, Tol,
-                         hyper_update_n0, hyper_update_dn, fudge, unif_stop, seed, device)
+                         hyper_update_n0, hyper_update_dn, fudge, unif_stop, seed, device, engine_factory)
     vb = [vb_iterate(irun, bundle) for irun in range(1, nrun + 1)]               # :260-261
     return select_best(vb, bundle["ranks"])

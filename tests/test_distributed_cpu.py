@@ -1,0 +1,84 @@
+"""N > 1 paths over gloo on the CPU (world_size 2): the cell-partition protocol and the sharded
+rank sweep, with the numpy engine standing in for the HIP engine."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+HY = {"aw": 1.2, "bw": 0.9, "ah": 0.8, "bh": 1.5}
+
+
+def _data():
+    from ccfindr_amd import synth
+    return synth.drop_empty(synth.simulate_data(50, (30, 45), seed=6, sparse=False))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fake_engine import NumpyPhaseEngine
+        from ccfindr_amd import parallel, synth
+        X = _data()
+        n, m = X.shape
+        r = 3
+        wh = synth.random_state(n, m, r, HY, seed=9)
+        # --- cell-partitioned factorisation
+        cols = parallel.cell_partition(m, world)[rank]
+        eng = parallel.CellPartitionedEngine(X, r, engine=NumpyPhaseEngine(X, r, cols=cols, m_global=m))
+        eng.set_state(wh["lw"], wh["lh"], wh["eh"])
+        trace = [eng.step(HY) for _ in range(6)]
+        state = eng.get_state()
+        # --- sharded rank sweep
+        res = parallel.vb_factorize_sharded(X, ranks=[2, 3, 4], nrun=2, Itmax=25, seed=11,
+                                            engine_factory=lambda M, rk: NumpyPhaseEngine(X, rk))
+        q.put((rank, trace, state, (res.ranks, res.measure, res.nsteps, [b.copy() for b in res.basis])))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_cell_partition_and_sharded_sweep_world2():
+    sys.path.insert(0, HERE)
+    from fake_engine import NumpyPhaseEngine
+    import ccfindr_amd as C
+    from ccfindr_amd import synth
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(k, 2, port, q)) for k in range(2)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=240) for _ in procs], key=lambda o: o[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+
+    X = _data()
+    n, m = X.shape
+    wh = synth.random_state(n, m, 3, HY, seed=9)
+    ref = NumpyPhaseEngine(X, 3)
+    ref.set_state(wh["lw"], wh["lh"], wh["eh"])
+    ref_trace = [ref.step(HY) for _ in range(6)]
+    ref_state = ref.get_state()
+    for rank, trace, state, _ in outs:
+        for (lkh, st), (lkh0, st0) in zip(trace, ref_trace):
+            assert lkh == pytest.approx(lkh0, rel=1e-12)
+            assert np.allclose(st, st0, rtol=1e-12)
+        for k in ref_state:                                   # lh/eh/dh are all-gathered to full width
+            assert state[k].shape == ref_state[k].shape
+            assert np.allclose(state[k], ref_state[k], rtol=1e-11), k
+    assert outs[0][1] == outs[1][1]                           # identical on every partition
+
+    serial = C.vb_factorize(X, ranks=[2, 3, 4], nrun=2, verbose=0, Itmax=25, seed=11,
+                            engine_factory=lambda M, rk: NumpyPhaseEngine(X, rk))
+    for rank, _, _, (ranks, measure, nsteps, basis) in outs:
+        assert ranks == serial.ranks and nsteps == serial.nsteps
+        assert measure["lml"] == serial.measure["lml"]        # same units, same seeds: bit-identical
+        for a, b in zip(basis, serial.basis):
+            assert np.array_equal(a, b)
