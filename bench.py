@@ -62,11 +62,24 @@ def algorithmic_bytes(n, m, r, nnz):
     return bytes_iter, sweep
 
 
+def usable_cores():
+    """Host cores this process may really use: affinity mask, cgroup quota, and the GPU box's
+    stated share of 16 cores per GPU (asking OpenMP for all 128 visible threads oversubscribes it)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
 def cpu_baseline(X, r, wh0, nsteps):
-    """The oracle's stored-entries restatement (OpenMP, all host cores) on the same workload."""
+    """The oracle's stored-entries restatement (OpenMP) on the same workload."""
     from oracle import vbnmf_oracle as O
     n, m = X.shape
-    cores = int(O.lib().oracle_max_threads())
+    cores = min(usable_cores(), int(O.lib().oracle_max_threads()))
     p, i, x = X.indptr, X.indices, X.data
     wh = wh0
     lk = []
