@@ -85,8 +85,11 @@ inline int padded_rank(int r) { return (r + 1) & ~1; }
 constexpr int lds_row_bytes(int R) { return ((R / 2) | 1) * 16; }
 // LDS the sweep keeps for itself in front of the factor block (the 128-entry ln table).
 constexpr int kLdsReserveBytes = 2048;
-// Threads per workgroup of the sweep kernel at padded rank R.
-constexpr int sweep_threads(int R) { return R <= 4 ? 1024 : (R <= 10 ? 768 : 512); }
+// Threads per workgroup of the sweep kernel at padded rank R: as many waves per SIMD as the
+// kernel's register need (factor row + accumulators + two gathered rows, ~14 R + 20 VGPRs) allows
+// without spilling: 4 waves/SIMD up to R = 4, 3 up to 10, 2 up to 26, 1 beyond (spills at 2 waves
+// made R = 32 ten times slower).
+constexpr int sweep_threads(int R) { return R <= 4 ? 1024 : (R <= 10 ? 768 : (R <= 26 ? 512 : 256)); }
 // Default block width / task length for a side at padded rank R; n_wg <= 0 picks the default (256).
 LayoutParams default_layout_params(int64_t n_major, int64_t n_minor, int R, int n_wg = 0);
 

@@ -187,8 +187,20 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
             // Slice widths are multiples of 8: two 4-entry groups per trip, the loads of the
             // next trip issued before this trip's arithmetic, LDS rows fetched one entry ahead.
             const int np = ng >> 1;
-            double2 g0[R / 2], g1[R / 2];
-            if (!WIDE) {
+            double2 g0[R / 2];
+            if (R > 28 && !WIDE) {
+                // very large ranks: the factor row, the accumulators and ONE gathered row already fill
+                // the register file, so no second row buffer and no look-ahead here
+                const uint4 *E = reinterpret_cast<const uint4 *>(S.packed + off) + lane;
+                for (int g = 0; g < ng; g++) {
+                    const Group4 a = unpack4<R>(E[(size_t)g * 64]);
+                    lds_row<R>(ldsG, a.o0, g0); sweep_entry<R>(T, ldsG, g0, (double)a.c0, LOGTERM);
+                    lds_row<R>(ldsG, a.o1, g0); sweep_entry<R>(T, ldsG, g0, (double)a.c1, LOGTERM);
+                    lds_row<R>(ldsG, a.o2, g0); sweep_entry<R>(T, ldsG, g0, (double)a.c2, LOGTERM);
+                    lds_row<R>(ldsG, a.o3, g0); sweep_entry<R>(T, ldsG, g0, (double)a.c3, LOGTERM);
+                }
+            } else if (!WIDE) {
+                double2 g1[R / 2];
                 const uint4 *E = reinterpret_cast<const uint4 *>(S.packed + off) + lane;
                 Group4 a = unpack4<R>(E[0]), b = unpack4<R>(E[64]);
                 lds_row<R>(ldsG, a.o0, g0);
@@ -221,6 +233,7 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
                 }
 #undef VBNMF_FENCE
             } else {
+                double2 g1[R / 2];
                 const uint4 *E = reinterpret_cast<const uint4 *>(S.widx + off) + lane;
                 const double2 *V = reinterpret_cast<const double2 *>(S.wval + off) + lane * 2;
                 for (int g = 0; g < ng; g++) {
