@@ -70,6 +70,8 @@ SIGNATURES = {
     "vbnmf_engine_reduce_buffer": (ctypes.c_int, [_VP, _VPP, c_int64_p]),
     "vbnmf_engine_step_finish": (ctypes.c_int, [_VP, c_double_p, c_double_p]),
     "vbnmf_engine_state_finish": (ctypes.c_int, [_VP]),
+    "vbnmf_engine_run": (ctypes.c_int, [_VP, c_double_p, _D, _I32, _D, _I32, _I32, c_int32_p, c_int32_p, c_double_p,
+                                        c_double_p, c_int32_p, c_double_p, _I64]),
     "vbnmf_engine_get_state": (ctypes.c_int, [_VP] + [c_double_p] * 6),
     "vbnmf_engine_get_stream": (ctypes.c_int, [_VP, _VPP]),
     "vbnmf_engine_set_stream": (ctypes.c_int, [_VP, _VP]),

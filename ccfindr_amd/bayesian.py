@@ -224,7 +224,13 @@ def vb_run_rank(irun, rank, bundle):
         eng.set_state(wh0["lw"], wh0["lh"], wh0["eh"])
         lk0 = 0.0
         it = 0
-        for it in range(1, bundle["Itmax"] + 1):                                 # :337
+        device_loop = bundle.get("device_loop", True) and verbose < 3 and hasattr(eng, "run")
+        if device_loop:
+            # the whole loop below, driven by the device (same rules, no host round trip per step)
+            out = eng.run(hyper, Itmax=bundle["Itmax"], Tol=bundle["Tol"], n0=bundle["hyper_update_n0"],
+                          dn=bundle["hyper_update_dn"], flags=bundle["hyper_update"], fudge=bundle["fudge"])
+            it, lk0, hyper = out["it"], out["lk0"], out["hyper"]
+        for it in (() if device_loop else range(1, bundle["Itmax"] + 1)):       # :337
             lkh, stats = eng.step(hyper, bundle["fudge"])                        # :339
             if it > bundle["hyper_update_n0"] and it % bundle["hyper_update_dn"] == 0:   # :342
                 hyper = hyper_update(bundle["hyper_update"], stats, hyper, Niter=100, Tol=1e-3)
@@ -335,7 +341,7 @@ def make_bundle(mat, ranks, nrun, verbose, initializer, Itmax, hyper_update, gam
 def vb_factorize(mat, ranks=2, nrun=1, verbose=2, progress_bar=True, initializer="random", Itmax=10000,
                  hyper_update=(True, True, True, True), gamma_a=1, gamma_b=1, Tol=1e-5,
                  hyper_update_n0=10, hyper_update_dn=1, connectivity=False, fudge=None, ncores=1,
-                 useC=True, unif_stop=True, seed=None, device=0, engine_factory=None):
+                 useC=True, unif_stop=True, seed=None, device=0, engine_factory=None, device_loop=True):
     """Bayesian NMF of a count matrix on the MI355X engine; reference R/bayesian.R:229-301.
 
     ``mat`` is the genes x cells count matrix (dense, scipy sparse, or ``CountMatrix``).
@@ -351,5 +357,6 @@ def vb_factorize(mat, ranks=2, nrun=1, verbose=2, progress_bar=True, initializer
         warnings.warn("connectivity/dispersion are outside the VB update path and are not computed")
     bundle = make_bundle(mat, ranks, nrun, verbose, initializer, Itmax, hyper_update, gamma_a, gamma_b, Tol,
                          hyper_update_n0, hyper_update_dn, fudge, unif_stop, seed, device, engine_factory)
+    bundle["device_loop"] = bool(device_loop)      # False: step from the host (the loop below, literally)
     vb = [vb_iterate(irun, bundle) for irun in range(1, nrun + 1)]               # :260-261
     return select_best(vb, bundle["ranks"])

@@ -82,6 +82,8 @@ struct vbnmf_engine {
     double *h_out_dev = nullptr;      // device address of h_out
     double seq = 0.0;
     LogTabEntry *logtab = nullptr;    // [128] ln table of the sweep
+    LoopCtl *ctl = nullptr;           // control block of the device-driven loop
+    bool run_active = false;
     unsigned long long *dbg = nullptr;   // diagnostic timestamps of the sweep (VBNMF_DEBUG_TIMES=1)
     size_t dbg_count = 0;
     size_t lds_bytes = 0;
@@ -140,6 +142,7 @@ SweepSide sweep_side_args(const vbnmf_engine *e, const DeviceSide &S, bool gene_
     P.logterm = gene_side ? 1 : 0;
     P.n_wg = S.n_wg;
     P.logtab = e->logtab;
+    P.stop = e->run_active ? &e->ctl->stop : nullptr;
     P.dbg = e->dbg ? e->dbg + (gene_side ? 0 : e->dbg_count / 2) : nullptr;
     return P;
 }
@@ -189,9 +192,11 @@ int launch_sweep(vbnmf_engine *e)
     return VBNMF_OK;
 }
 
-int launch_update(vbnmf_engine *e, bool gene_side, double a, double b, double fudge)
+// ctl != nullptr: device-driven loop, the hyper-parameters are read from the control block on the device
+int launch_update(vbnmf_engine *e, bool gene_side, double a, double b, double fudge, const LoopCtl *ctl = nullptr)
 {
-    const double lga = -std::lgamma(a) + a * std::log(a / b);     // reference :82 / :87
+    const double lga = ctl ? 0.0 : -std::lgamma(a) + a * std::log(a / b);     // reference :82 / :87
+    const int side = gene_side ? 0 : 1;
     const bool dense = gene_side && e->partitioned;               // statistics already summed into `red`
     const DeviceSide &S = gene_side ? e->A : e->B;
     const double *acc = dense ? e->red : S.part;
@@ -205,7 +210,7 @@ int launch_update(vbnmf_engine *e, bool gene_side, double a, double b, double fu
     double *ev = gene_side ? e->ew : e->eh, *d = gene_side ? e->dw : e->dh;
     double *bp = gene_side ? e->bpW : e->bpH;
     switch (e->R) {
-#define X(RR) case RR: hipLaunchKernelGGL((k_update<RR>), dim3(kUpdateBlocks), dim3(kUpdateThreads), 0, e->stream, acc, inv_ptr, inv_task, nmaj, e->r, other, other_bp, other_nb, a, b, lga, fudge, l, ll, ev, d, bp); break;
+#define X(RR) case RR: hipLaunchKernelGGL((k_update<RR>), dim3(kUpdateBlocks), dim3(kUpdateThreads), 0, e->stream, acc, inv_ptr, inv_task, nmaj, e->r, other, other_bp, other_nb, a, b, lga, fudge, l, ll, ev, d, bp, ctl, side); break;
         VBNMF_FOR_EACH_R(X)
 #undef X
         default: return fail(VBNMF_ERR_BAD_ARG, "unsupported padded rank %d", e->R);
@@ -333,7 +338,7 @@ void vbnmf_engine_destroy(vbnmf_engine *e)
     (void)hipFree(e->lw); (void)hipFree(e->llw); (void)hipFree(e->ew); (void)hipFree(e->dw);
     (void)hipFree(e->lh); (void)hipFree(e->llh); (void)hipFree(e->eh); (void)hipFree(e->dh);
     (void)hipFree(e->epart); (void)hipFree(e->bpW); (void)hipFree(e->bpH);
-    (void)hipFree(e->red); (void)hipFree(e->d_out); (void)hipFree(e->dbg); (void)hipFree(e->logtab);
+    (void)hipFree(e->red); (void)hipFree(e->d_out); (void)hipFree(e->dbg); (void)hipFree(e->logtab); (void)hipFree(e->ctl);
     if (e->h_out) (void)hipHostFree(e->h_out);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
@@ -391,6 +396,7 @@ int vbnmf_engine_create_part(const vbnmf_matrix *X, int64_t cb, int64_t ce, int6
         std::vector<LogTabEntry> tab(kLogTabSize);
         fill_log_table(tab.data());
         if ((rc = dev_upload(&e->logtab, tab))) return bail(rc);
+        if ((rc = dev_alloc(&e->ctl, 1))) return bail(rc);
     }
 
     const size_t nR = (size_t)e->n * e->R, mR = (size_t)e->m * e->R;
@@ -560,6 +566,84 @@ int vbnmf_engine_step(vbnmf_engine *e, double aw, double bw, double ah, double b
     if (e && e->partitioned) return fail(VBNMF_ERR_STATE, "a partitioned engine needs step_local / all-reduce / step_finish");
     if (int rc = vbnmf_engine_step_local(e, aw, bw, ah, bh, fudge)) return rc;
     return vbnmf_engine_step_finish(e, lkh, stats);
+}
+
+// Device-driven form of the per-rank loop of vb_iterate (reference R/bayesian.R:336-352).
+int vbnmf_engine_run(vbnmf_engine *e, double *hyper, double fudge, int32_t max_it, double tol, int32_t n0, int32_t dn,
+                     const int32_t *flags, int32_t *it_out, double *lk0_out, double *lkh_out, int32_t *reason_out,
+                     double *history, int64_t history_rows)
+{
+    if (!e || !hyper || !flags) return fail(VBNMF_ERR_BAD_ARG, "NULL argument");
+    if (e->partitioned) return fail(VBNMF_ERR_STATE, "the device-driven loop needs an unpartitioned engine");
+    if (!e->has_state || !e->stats_ready) return fail(VBNMF_ERR_STATE, "run before set_state");
+    if (e->step_pending) return fail(VBNMF_ERR_STATE, "run between step_local and step_finish");
+    if (max_it < 1 || dn < 1) return fail(VBNMF_ERR_BAD_ARG, "max_it and dn must be >= 1");
+    if (history && history_rows < max_it) return fail(VBNMF_ERR_BAD_ARG, "history needs max_it rows of 9 doubles");
+    if (int rc = use_device(e)) return rc;
+
+    LoopCtl c{};
+    for (int q = 0; q < 4; q++) { c.hyper[q] = hyper[q]; c.flags[q] = flags[q] ? 1 : 0; }
+    c.lk0 = 0.0;                                                   // :336
+    c.tol = tol; c.max_it = max_it; c.n0 = n0; c.dn = dn;
+    double *d_hist = nullptr;
+    if (history) { if (int rc = dev_alloc(&d_hist, (size_t)max_it * 9)) return rc; }
+    auto cleanup = [&](int rc) { e->run_active = false; (void)hipFree(d_hist); return rc; };
+    hipError_t he = hipMemcpyAsync(e->ctl, &c, sizeof c, hipMemcpyHostToDevice, e->stream);
+    if (he != hipSuccess) return cleanup(fail(VBNMF_ERR_HIP, "hipMemcpyAsync failed: %s", hipGetErrorString(he)));
+    he = hipStreamSynchronize(e->stream);                          // `c` is on this stack frame
+    if (he != hipSuccess) return cleanup(fail(VBNMF_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(he)));
+    volatile double *ho = e->h_out;
+    ho[5] = 0.0; ho[6] = 0.0; ho[7] = 0.0;
+    e->run_active = true;
+
+    // Steps are queued ahead of the device (two batches deep) so the host never sits on the critical
+    // path; kernels of steps queued beyond the break return at once.
+    const int batch = 8;
+    const int64_t nep = 2 * (int64_t)e->n_wg;
+    int queued = 0;
+    bool stopped = false;
+    while (!stopped) {
+        const int done = (int)ho[7];
+        while (queued < max_it && queued - done < 2 * batch) {
+            int rc = launch_update(e, true, 0, 0, fudge, e->ctl);
+            if (!rc) rc = launch_update(e, false, 0, 0, fudge, e->ctl);
+            if (!rc) rc = launch_sweep(e);
+            if (rc) return cleanup(rc);
+            switch (e->R) {
+#define X(RR) case RR: hipLaunchKernelGGL((k_control<RR>), dim3(1), dim3(1024), 0, e->stream, e->bpW, e->bpH, kUpdateBlocks, e->epart, nep, e->lgx, e->r, (double)e->n, (double)e->m_global, e->ctl, d_hist, e->h_out_dev); break;
+                VBNMF_FOR_EACH_R(X)
+#undef X
+                default: return cleanup(fail(VBNMF_ERR_BAD_ARG, "unsupported padded rank %d", e->R));
+            }
+            if ((he = hipGetLastError()) != hipSuccess) return cleanup(fail(VBNMF_ERR_HIP, "k_control launch failed: %s", hipGetErrorString(he)));
+            queued++;
+        }
+        // wait for progress: a reason code, or the device catching up with the queue
+        long spins = 0;
+        while (true) {
+            if (ho[6] != 0.0) { stopped = true; break; }
+            const int d2 = (int)ho[7];
+            if (d2 >= max_it) { stopped = true; break; }
+            if (queued < max_it && queued - d2 < 2 * batch) break;          // room to queue more
+            if ((++spins & 0xFFFF) == 0) {
+                hipError_t q = hipStreamQuery(e->stream);
+                if (q != hipSuccess && q != hipErrorNotReady) return cleanup(fail(VBNMF_ERR_HIP, "the loop failed on the device: %s", hipGetErrorString(q)));
+                if (q == hipSuccess && ho[6] == 0.0 && (int)ho[7] < queued) return cleanup(fail(VBNMF_ERR_HIP, "the device went idle before the queued steps finished"));
+            }
+        }
+    }
+    he = hipStreamSynchronize(e->stream);
+    if (he != hipSuccess) return cleanup(fail(VBNMF_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(he)));
+    he = hipMemcpy(&c, e->ctl, sizeof c, hipMemcpyDeviceToHost);
+    if (he == hipSuccess && history && c.it > 0) he = hipMemcpy(history, d_hist, (size_t)c.it * 9 * sizeof(double), hipMemcpyDeviceToHost);
+    if (he != hipSuccess) return cleanup(fail(VBNMF_ERR_HIP, "reading the loop result failed: %s", hipGetErrorString(he)));
+    for (int q = 0; q < 4; q++) hyper[q] = c.hyper[q];
+    if (it_out) *it_out = c.it;
+    if (lk0_out) *lk0_out = c.lk0;
+    if (lkh_out) *lkh_out = c.lkh;
+    if (reason_out) *reason_out = c.reason;
+    e->seq = 0.0; e->h_out[7] = 0.0;                                // the step path's sequence flag restarts
+    return cleanup(VBNMF_OK);
 }
 
 int vbnmf_engine_get_state(vbnmf_engine *e, double *lw, double *lh, double *ew, double *eh, double *dw, double *dh)

@@ -55,6 +55,7 @@ struct SweepSide {
     int32_t logterm;               // this side also accumulates sum x*log(wth)
     int32_t n_wg;
     const LogTabEntry *logtab;     // [128] ln table (staged at the front of LDS)
+    const int32_t *stop;           // device-driven loop: the sweep returns at once when *stop != 0 (or null)
     unsigned long long *dbg;       // diagnostic: [n_wg][2 + 2*waves] 100 MHz timestamps, or null
 };
 
@@ -290,6 +291,7 @@ template <int R, bool WIDE, int NT>
 __global__ __launch_bounds__(NT) void k_sweep(const SweepSide A, const SweepSide B)
 {
     extern __shared__ double2 ldsG[];
+    if (A.stop && *A.stop) return;               // the driver loop has ended: leave the statistics as they are
     sweep_side<R, WIDE, true, NT>(A, ldsG);      // lanes own genes: statistics sw + the sum x log(wth)
     sweep_side<R, WIDE, false, NT>(B, ldsG);     // lanes own cells: statistics sh
 }
@@ -352,16 +354,37 @@ __device__ __forceinline__ void bp_colsums(const double *__restrict__ bp, int nb
 // partials other_bp[other_nb][R+2], reduced here in the prologue.
 // Block partials out: bp[block][0..R) = sum e per k, bp[block][R] = sum term, bp[block][R+1] = sum log l.
 // ------------------------------------------------------------------------------------
+// Device-resident driver loop (reference R/bayesian.R:336-352): the hyper-parameters, the lagging
+// evidence lk0, the iteration counter and the stop flag live here; once `stop` is set every kernel
+// of the remaining queued steps returns at once, so the state stays exactly as the break left it.
+struct LoopCtl {
+    double hyper[4];               // aw, bw, ah, bh (updated in place from step n0+1 on)
+    double lk0, lkh;
+    double stats[4];               // mean log lw, mean log lh, mean ew, mean eh of the last step
+    double tol;
+    int32_t it, stop, reason;      // reason: 1 NaN evidence, 2 converged, 3 hyper Newton failed, 4 Itmax
+    int32_t max_it, n0, dn;
+    int32_t flags[4];              // hyper.update
+};
+
 template <int R>
 __global__ __launch_bounds__(kUpdateThreads) void k_update(
     const double *__restrict__ acc, const int32_t *__restrict__ inv_ptr, const uint32_t *__restrict__ inv_task,
     int64_t nmaj, int r, const double *__restrict__ other, const double *__restrict__ other_bp, int other_nb,
     double a, double b, double lga, double fudge,
-    double *__restrict__ l, double *__restrict__ ll, double *__restrict__ e, double *__restrict__ d, double *__restrict__ bp)
+    double *__restrict__ l, double *__restrict__ ll, double *__restrict__ e, double *__restrict__ d, double *__restrict__ bp,
+    const LoopCtl *__restrict__ ctl, int side)
 {
     constexpr int RB = kUpdateThreads / R;       // majors per pass
     __shared__ double s_other[R + 2];
     __shared__ double s_e[kUpdateThreads], s_t[kUpdateThreads], s_l[kUpdateThreads];
+    if (ctl) {                                   // device-driven loop: hyper-parameters come from the control block
+        if (ctl->stop) return;
+        a = ctl->hyper[2 * side]; b = ctl->hyper[2 * side + 1];
+        double psi_a, lg_a;
+        dev_psi_lgamma(a, &psi_a, &lg_a);
+        lga = -lg_a + a * log(a / b);            // reference src/vbnmf_update.cpp:82 / :87
+    }
     const int t = threadIdx.x;
     if (other_nb > 0) bp_colsums(other_bp, other_nb, R + 2, s_other, kUpdateThreads);
     else if (t < R) s_other[t] = other[t];
@@ -525,6 +548,96 @@ __global__ __launch_bounds__(1024) void k_final(const double *__restrict__ bpW, 
         __threadfence_system();
         reinterpret_cast<volatile double *>(out_host)[7] = seq;
     }
+}
+
+// ------------------------------------------------------------------------------------
+// Device-resident driver loop: hyper_update (reference R/bayesian.R:2-53) and the loop control of
+// vb_iterate (R/bayesian.R:342-348) after each step, by one thread.
+// ------------------------------------------------------------------------------------
+__device__ inline double dev_trigamma(double x)
+{
+    double s = 0.0;
+    while (x < 10.0) { s += 1.0 / (x * x); x += 1.0; }
+    const double xi = 1.0 / x, y = xi * xi;
+    const double ser = xi * y * (1.0 / 6 - y * (1.0 / 30 - y * (1.0 / 42 - y * (1.0 / 30 - y * (5.0 / 66 - y * (691.0 / 2730 - y * (7.0 / 6)))))));
+    return s + xi + 0.5 * y + ser;
+}
+__device__ inline double dev_digamma1(double x) { double p, g; dev_psi_lgamma(x, &p, &g); return (x > 0.0) ? p : __builtin_nan(""); }
+
+// Returns 0, or 1 when the Newton iteration does not converge ("Hyper-parameter update failed to converge", :43).
+__device__ inline int dev_hyper_update(const int32_t *flags, const double *stats, double *hyper)
+{
+    if (flags[0] + flags[1] + flags[2] + flags[3] == 0) return 0;                          // :4
+    double aw0 = hyper[0], ah0 = hyper[2];
+    const double lwm = stats[0], lhm = stats[1], ewm = stats[2], ehm = stats[3];           // :8-11
+    const double bw0 = hyper[1], bh0 = hyper[3];
+    double aw1 = aw0, ah1 = ah0;
+    if (flags[0] + flags[2] > 0) {                                                         // :15
+        int i = 1;
+        while (i < 100) {                                                                  // Niter = 100 (:343)
+            double dw = flags[0] ? (log(aw0) - dev_digamma1(aw0) - ewm / bw0 + 1.0 + lwm - log(bw0)) / (1.0 / aw0 - dev_trigamma(aw0)) : 0.0;
+            double dh = flags[2] ? (log(ah0) - dev_digamma1(ah0) - ehm / bh0 + 1.0 + lhm - log(bh0)) / (1.0 / ah0 - dev_trigamma(ah0)) : 0.0;
+            aw1 = aw0 - dw; ah1 = ah0 - dh;
+            while (aw1 <= 0.0) { dw *= 0.5; aw1 = aw0 - dw; }                              // :28-31
+            while (ah1 <= 0.0) { dh *= 0.5; ah1 = ah0 - dh; }                              // :32-35
+            const double u = 1.0 - aw1 / aw0, v = 1.0 - ah1 / ah0;
+            if (u * u + v * v < 1e-3) break;                                               // Tol = 1e-3 (:344)
+            aw0 = aw1; ah0 = ah1; i++;
+        }
+        if (i == 100) return 1;
+    }
+    hyper[0] = aw1; hyper[1] = flags[1] ? ewm : bw0;                                       // :48-49
+    hyper[2] = ah1; hyper[3] = ehm;                                                        // :50-51 (both branches assign ehm)
+    return 0;
+}
+
+// One block after each sweep of a device-driven loop: the reductions of k_final, then
+//   it <- it+1 ; hyper_update if it > n0 and it %% dn == 0 (:342-344) ; break on NaN (:345) ;
+//   break if it > 1, it > n0, lkh >= lk0 and |1 - lkh/lk0| < Tol (:346-347, lk0 NOT refreshed) ; lk0 <- lkh (:348).
+// history row it-1 = [lkh, 4 statistics, 4 hyper-parameters after the update]; out_host = [lkh, 4 stats, it, reason, it].
+template <int R>
+__global__ __launch_bounds__(1024) void k_control(const double *__restrict__ bpW, const double *__restrict__ bpH, int nb,
+                                                  const double *__restrict__ epart, int64_t nepart, double lgx, int r,
+                                                  double n, double m_global, LoopCtl *ctl, double *__restrict__ history,
+                                                  double *__restrict__ out_host)
+{
+    if (ctl->stop) return;
+    __shared__ double sW[R + 2], sT[R + 4];
+    __shared__ double sm[1024];
+    bp_colsums(bpW, nb, R + 2, sW, 1024);
+    bp_colsums(bpH, nb, R + 2, sT, 1024);
+    const double data = block_vec_sum(epart, nepart, sm);
+    if (threadIdx.x != 0) return;
+    double cross = 0.0, sew = 0.0, seh = 0.0;
+    for (int k = 0; k < r; k++) { cross += sW[k] * sT[k]; sew += sW[k]; seh += sT[k]; }
+    const double U = -cross - data - lgx + sW[R] + sT[R];
+    const double lkh = U / (n * m_global);
+    double st[4] = {sW[R + 1] / (n * r), sT[R + 1] / (m_global * r), sew / (n * r), seh / (m_global * r)};
+    const int it = ctl->it + 1;
+    int reason = 0;
+    if (it > ctl->n0 && it % ctl->dn == 0) {
+        if (dev_hyper_update(ctl->flags, st, ctl->hyper)) reason = 3;
+    }
+    const double lk0 = ctl->lk0;
+    if (!reason) {
+        if (lkh != lkh) reason = 1;
+        else if (it > 1 && it > ctl->n0 && lkh >= lk0 && fabs(1.0 - lkh / lk0) < ctl->tol) reason = 2;
+        else { ctl->lk0 = lkh; if (it >= ctl->max_it) reason = 4; }
+    }
+    ctl->it = it; ctl->lkh = lkh;
+    for (int q = 0; q < 4; q++) ctl->stats[q] = st[q];
+    if (history) {
+        double *h = history + (size_t)(it - 1) * 9;
+        h[0] = lkh;
+        for (int q = 0; q < 4; q++) { h[1 + q] = st[q]; h[5 + q] = ctl->hyper[q]; }
+    }
+    if (reason) { ctl->reason = reason; ctl->stop = 1; }
+    out_host[0] = lkh;
+    for (int q = 0; q < 4; q++) out_host[1 + q] = st[q];
+    out_host[5] = (double)it;
+    __threadfence_system();
+    reinterpret_cast<volatile double *>(out_host)[6] = (double)reason;
+    reinterpret_cast<volatile double *>(out_host)[7] = (double)it;
 }
 
 // Device-side evaluation of the special functions, for tests (tests/test_gpu_special.py).

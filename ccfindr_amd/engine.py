@@ -147,6 +147,26 @@ class VBEngine:
                                             ctypes.byref(lkh), st))
         return lkh.value, tuple(st)
 
+    def run(self, hyper, Itmax=10000, Tol=1e-5, n0=10, dn=1, flags=(True,) * 4, fudge=EPS, history=False):
+        """The per-rank loop of vb_iterate (reference R/bayesian.R:336-352) driven by the device.
+
+        Returns ``dict(it, lk0, lkh, hyper, reason, history)``; ``reason``: 1 NaN evidence, 2 converged,
+        3 hyper-parameter Newton failed (raised as RuntimeError, as the reference stops there), 4 Itmax.
+        ``history`` (optional): array [it, 9] = lkh, mean log lw, mean log lh, mean ew, mean eh, aw, bw, ah, bh."""
+        hy = (ctypes.c_double * 4)(*(float(hyper[k]) for k in ("aw", "bw", "ah", "bh")))
+        fl = (ctypes.c_int32 * 4)(*(1 if f else 0 for f in flags))
+        it, reason = ctypes.c_int32(), ctypes.c_int32()
+        lk0, lkh = ctypes.c_double(), ctypes.c_double()
+        hist = np.zeros((int(Itmax), 9)) if history else None
+        N.check(self._lib.vbnmf_engine_run(self._h, hy, float(fudge), int(Itmax), float(Tol), int(n0), int(dn), fl,
+                                           ctypes.byref(it), ctypes.byref(lk0), ctypes.byref(lkh), ctypes.byref(reason),
+                                           N.dptr(hist), int(Itmax) if history else 0))
+        if reason.value == 3:
+            raise RuntimeError("Hyper-parameter update failed to converge")      # reference R/bayesian.R:43
+        return {"it": it.value, "lk0": lk0.value, "lkh": lkh.value, "reason": reason.value,
+                "hyper": dict(zip(("aw", "bw", "ah", "bh"), (float(v) for v in hy))),
+                "history": hist[:it.value] if history else None}
+
     def step_local(self, hyper, fudge=EPS):
         N.check(self._lib.vbnmf_engine_step_local(self._h, hyper["aw"], hyper["bw"], hyper["ah"], hyper["bh"], float(fudge)))
 

@@ -127,6 +127,22 @@ int vbnmf_engine_step_finish(vbnmf_engine *e, double *lkh, double *stats);
  * set_state leaves them in the reduce buffer; all-reduce it, then call this. */
 int vbnmf_engine_state_finish(vbnmf_engine *e);
 
+/* The per-rank loop of vb_iterate (R/bayesian.R:336-352) run by the device: up to max_it steps with
+ *   - hyper_update (R/bayesian.R:2-53, Niter = 100, Tol = 1e-3) after every step `it` with it > n0 and
+ *     it %% dn == 0, `flags` = hyper.update (4 logicals),
+ *   - break when lkh is NaN (:345), or when it > 1, it > n0, lkh >= lk0 and |1 - lkh/lk0| < tol (:346-347;
+ *     lk0 then keeps the PREVIOUS step's evidence, as the reference leaves it), else lk0 <- lkh (:348).
+ * Steps are queued ahead of the device, so no host round trip sits between two steps; kernels queued
+ * beyond the break return at once and the state stays exactly as the breaking step left it.
+ * hyper[4] = aw, bw, ah, bh (in: initial, out: final).  Outputs (any may be NULL): it = steps done,
+ * lk0, lkh of the last step, reason (1 NaN, 2 converged, 3 hyper Newton did not converge -- the
+ * reference stops with an error there, :43 -- 4 max_it reached), history[it][9] = lkh, mean log lw,
+ * mean log lh, mean ew, mean eh, then aw, bw, ah, bh after that step's update (history_rows >= max_it).
+ * Unpartitioned engines only. */
+int vbnmf_engine_run(vbnmf_engine *e, double *hyper, double fudge, int32_t max_it, double tol, int32_t n0,
+                     int32_t dn, const int32_t *flags, int32_t *it, double *lk0, double *lkh, int32_t *reason,
+                     double *history, int64_t history_rows);
+
 /* Download the current wh members (any pointer may be NULL):
  * lw, ew, dw : n x r ; lh, eh, dh : r x m_local.  dw, dh are variances, as the reference
  * returns them (src/vbnmf_update.cpp:46,56); the R driver takes sqrt later (R/bayesian.R:382-383). */
