@@ -83,8 +83,9 @@ inline int padded_rank(int r) { return (r + 1) & ~1; }
 // Bytes of one factor row in the sweep's LDS image: R doubles, padded to an odd number of 16-byte
 // bank slots so that rows congruent mod 16 (and only those) start in the same slot.
 constexpr int lds_row_bytes(int R) { return ((R / 2) | 1) * 16; }
-// LDS the sweep keeps for itself in front of the factor block (the 128-entry ln table).
-constexpr int kLdsReserveBytes = 2048;
+// LDS the sweep keeps for itself in front of the factor block: the 128-entry ln table (2048 B),
+// 256 per-slice evidence partials (2048 B) and the slice ticket counter (16 B).
+constexpr int kLdsReserveBytes = 4112;
 // Threads per workgroup of the sweep kernel at padded rank R: as many waves per SIMD as the
 // kernel's register need (factor row + accumulators + two gathered rows, ~14 R + 20 VGPRs) allows
 // without spilling: 4 waves/SIMD up to R = 4, 3 up to 10, 2 up to 26, 1 beyond (spills at 2 waves

@@ -391,7 +391,8 @@ int vbnmf_engine_create_part(const vbnmf_matrix *X, int64_t cb, int64_t ce, int6
     }
     if (rc) return bail(rc);
     e->lgx = (cb == 0 && ce == X->M.m) ? X->lgx : sum_lgamma_x1(X->M, cb, ce);
-    e->lds_bytes = kLdsTabBytes + (size_t)std::max(e->A.block_width, e->B.block_width) * lds_row_bytes(e->R);
+    static_assert(kLdsRowBase == kLdsReserveBytes, "host and device disagree on the sweep's LDS reserve");
+    e->lds_bytes = kLdsRowBase + (size_t)std::max(e->A.block_width, e->B.block_width) * lds_row_bytes(e->R);
     {
         std::vector<LogTabEntry> tab(kLogTabSize);
         fill_log_table(tab.data());

@@ -92,15 +92,20 @@ __device__ __forceinline__ void pin(Group4 &g)
 {
     asm volatile("" : "+v"(g.o0), "+v"(g.o1), "+v"(g.o2), "+v"(g.o3), "+v"(g.c0), "+v"(g.c1), "+v"(g.c2), "+v"(g.c3));
 }
-// LDS image of the sweep: [0, kLdsTabBytes) the ln table, then the staged factor block.
+// LDS image of the sweep: [0, kLdsTabBytes) the ln table, then kLdsEvSlots per-slice evidence
+// partials, the slice ticket counter, and from kLdsRowBase on the staged factor block.
 constexpr uint32_t kLdsTabBytes = kLogTabSize * sizeof(LogTabEntry);
+constexpr int kLdsEvSlots = 256;
+constexpr uint32_t kLdsEvBase = kLdsTabBytes;
+constexpr uint32_t kLdsCtrBase = kLdsEvBase + kLdsEvSlots * sizeof(double);
+constexpr uint32_t kLdsRowBase = kLdsCtrBase + 16;
 template <int R>
 __device__ __forceinline__ Group4 unpack4(const uint4 e)
 {
     constexpr uint32_t kRow = ((R / 2) | 1) * 16;          // LDS row stride: odd number of 16-byte slots
     Group4 g;
-    g.o0 = (e.x & 0xFFFFu) * kRow + kLdsTabBytes; g.o1 = (e.y & 0xFFFFu) * kRow + kLdsTabBytes;
-    g.o2 = (e.z & 0xFFFFu) * kRow + kLdsTabBytes; g.o3 = (e.w & 0xFFFFu) * kRow + kLdsTabBytes;
+    g.o0 = (e.x & 0xFFFFu) * kRow + kLdsRowBase; g.o1 = (e.y & 0xFFFFu) * kRow + kLdsRowBase;
+    g.o2 = (e.z & 0xFFFFu) * kRow + kLdsRowBase; g.o3 = (e.w & 0xFFFFu) * kRow + kLdsRowBase;
     g.c0 = e.x >> 16; g.c1 = e.y >> 16; g.c2 = e.z >> 16; g.c3 = e.w >> 16;
     return g;
 }
@@ -138,6 +143,16 @@ __device__ __forceinline__ void sweep_entry(SweepRegs<R> &S, const double2 *__re
 #endif
 }
 
+// Next slice ticket of the workgroup: lane 0 increments the LDS counter, every lane gets the value.
+// Kept out of line on purpose: inlined into the slice loop, hipcc (ROCm 7.2) merged the wave-uniform
+// exit test with its per-lane atomic rewrite into a loop nest that re-read a stale ticket and never ended.
+__device__ __attribute__((noinline)) int take_ticket(int *ticket)
+{
+    int i = 0;
+    if ((threadIdx.x & 63) == 0) i = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return __shfl(i, 0, 64);
+}
+
 template <int R, bool WIDE, bool LOGTERM, int NT>
 __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restrict__ ldsG)
 {
@@ -148,17 +163,20 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
     const int seg0 = S.wg_seg0[wg], seg1 = S.wg_seg0[wg + 1];
     if (S.dbg && lane == 0) S.dbg[(size_t)wg * (2 + 2 * (NT / 64)) + 2 + 2 * wave] = __builtin_amdgcn_s_memrealtime();
     if (S.dbg && threadIdx.x == 0) S.dbg[(size_t)wg * (2 + 2 * (NT / 64))] = __builtin_amdgcn_s_memrealtime();
-    double ev_wave = 0.0;                                  // this wave's evidence contributions, in slice order
+    double ev_wg = 0.0;                                    // this workgroup's evidence, summed in list order (thread 0)
+    double *ev_slot = reinterpret_cast<double *>(reinterpret_cast<char *>(ldsG) + kLdsEvBase);
+    int *ticket = reinterpret_cast<int *>(reinterpret_cast<char *>(ldsG) + kLdsCtrBase);
     for (int seg = seg0; seg < seg1; seg++) {
         const int blk = S.seg_block[seg];
         const int m0 = blk * S.block_width;
         const int cw = min(S.block_width, S.n_minor - m0);
         __syncthreads();                                   // readers of the previous block are done
+        if (threadIdx.x == 0) *ticket = 0;
         {
             constexpr int kSlots = (R / 2) | 1;            // LDS row stride in 16-byte slots (odd)
             const double2 *G2 = reinterpret_cast<const double2 *>(S.G + (size_t)m0 * R);
             const int cnt = cw * (R / 2);
-            double2 *rows = ldsG + kLdsTabBytes / sizeof(double2);
+            double2 *rows = ldsG + kLdsRowBase / sizeof(double2);
             for (int t = threadIdx.x; t < cnt; t += NT) {
                 const int row = t / (R / 2), kk = t - row * (R / 2);
                 rows[row * kSlots + kk] = G2[t];
@@ -166,9 +184,16 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
             if (threadIdx.x < kLogTabSize) ldsG[threadIdx.x] = reinterpret_cast<const double2 *>(S.logtab)[threadIdx.x];
         }
         __syncthreads();
-        const int i0 = S.segwave_ptr[seg * (NT / 64) + wave], i1 = S.segwave_ptr[seg * (NT / 64) + wave + 1];
-        for (int i = i0; i < i1; i++) {
-            const int s = S.segwave_slice[i];
+        // The waves pull slices from the segment's list (longest first) through an LDS ticket counter, in
+        // chunks of kLdsEvSlots so every slice's evidence partial has an LDS slot; after a chunk the slots
+        // are added in list order, so the sum does not depend on which wave ran which slice.
+        const int l0 = S.segwave_ptr[seg], l1 = S.segwave_ptr[seg + 1];
+        for (int c0 = l0; c0 < l1; c0 += kLdsEvSlots) {
+        const int cn = min(kLdsEvSlots, l1 - c0);
+        while (true) {
+            const int i = take_ticket(ticket);
+            if (i >= cn) break;
+            const int s = c0 + i;                          // slices are numbered in processing order
             const uint32_t M = S.task_major[(size_t)s * 64 + lane];
             const int ng = S.slice_width[s] >> 2;
             const int64_t off = S.slice_off[s];
@@ -240,12 +265,12 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
                 for (int g = 0; g < ng; g++) {
                     const uint4 c = E[(size_t)g * 64];
                     const double2 v0 = V[(size_t)g * 128], v1 = V[(size_t)g * 128 + 1];
-                    lds_row<R>(ldsG, c.x * (((R / 2) | 1) * 16) + kLdsTabBytes, g0);
-                    lds_row<R>(ldsG, c.y * (((R / 2) | 1) * 16) + kLdsTabBytes, g1);
+                    lds_row<R>(ldsG, c.x * (((R / 2) | 1) * 16) + kLdsRowBase, g0);
+                    lds_row<R>(ldsG, c.y * (((R / 2) | 1) * 16) + kLdsRowBase, g1);
                     sweep_entry<R>(T, ldsG, g0, v0.x, LOGTERM);
-                    lds_row<R>(ldsG, c.z * (((R / 2) | 1) * 16) + kLdsTabBytes, g0);
+                    lds_row<R>(ldsG, c.z * (((R / 2) | 1) * 16) + kLdsRowBase, g0);
                     sweep_entry<R>(T, ldsG, g1, v0.y, LOGTERM);
-                    lds_row<R>(ldsG, c.w * (((R / 2) | 1) * 16) + kLdsTabBytes, g1);
+                    lds_row<R>(ldsG, c.w * (((R / 2) | 1) * 16) + kLdsRowBase, g1);
                     sweep_entry<R>(T, ldsG, g0, v1.x, LOGTERM);
                     sweep_entry<R>(T, ldsG, g1, v1.y, LOGTERM);
                 }
@@ -270,19 +295,24 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
             }
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) ev += __shfl_down(ev, d, 64);
-            ev_wave += ev;                                 // meaningful in lane 0
+            if (lane == 0) ev_slot[i] = ev;                // this slice's evidence partial
+        }
+        // end of the chunk: add its slots in list order (wave 0: lane-strided, then a fixed shuffle tree)
+        __syncthreads();
+        if (wave == 0) {
+            double t = 0.0;
+            for (int q = lane; q < cn; q += 64) t += ev_slot[q];
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) t += __shfl_down(t, d, 64);
+            ev_wg += t;                                    // meaningful in thread 0
+            if (lane == 0) *ticket = 0;
+        }
+        __syncthreads();
         }
     }
     if (S.dbg && lane == 0) S.dbg[(size_t)wg * (2 + 2 * (NT / 64)) + 3 + 2 * wave] = __builtin_amdgcn_s_memrealtime();
-    // one evidence partial per workgroup: the waves' sums added in wave order
-    __syncthreads();                                       // all LDS reads of the last block are done
-    double *sm = reinterpret_cast<double *>(ldsG);
-    if (lane == 0) sm[wave] = ev_wave;
-    __syncthreads();
     if (threadIdx.x == 0) {
-        double t = 0.0;
-        for (int w = 0; w < NT / 64; w++) t += sm[w];
-        S.epart[wg] = t;
+        S.epart[wg] = ev_wg;                               // one evidence partial per workgroup and side
         if (S.dbg) S.dbg[(size_t)wg * (2 + 2 * (NT / 64)) + 1] = __builtin_amdgcn_s_memrealtime();
     }
 }
