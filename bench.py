@@ -34,6 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+FP64_PEAK_TFLOPS = 78.6      # MI355X fp64 vector peak (same guide); the sweep's arithmetic runs on the vector units
 HYPER = {"aw": 1.0, "bw": 1.0, "ah": 1.0, "bh": 1.0}
 
 
@@ -205,6 +206,10 @@ def main():
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "algorithmic_bytes_per_launch": bytes_sweep, "kernel_ms": sweep_s * 1e3,
                          "streamed_bytes_per_launch": info["stream_bytes_per_step"]},
+            # SURVEY.md section 8(d) asks for both fractions: algorithmic flops = 10 r per stored entry
+            "roofline_fp64": {"bound": "fp64-valu", "kernel": "k_sweep", "flops_per_launch": 10 * r * nnz,
+                              "achieved": (10 * r * nnz / sweep_s / 1e12) if sweep_cnt else None, "peak": FP64_PEAK_TFLOPS,
+                              "unit": "TFLOP/s", "frac": (10 * r * nnz / sweep_s / 1e12 / FP64_PEAK_TFLOPS) if sweep_cnt else None},
             "iteration_roofline": {"bytes_iter": bytes_iter, "achieved_GBs": bytes_iter * (value / units_per_step) / 1e9,
                                    "frac": bytes_iter * (value / units_per_step) / 1e9 / HBM_PEAK_GBS},
         }
