@@ -10,4 +10,6 @@ from .engine import EPS, CountMatrix, VBEngine  # noqa: F401
 from .bayesian import (VBResult, hyper_update, vb_factorize, vb_init, vb_iterate,  # noqa: F401
                        vbnmf_update)
 
+from .factorize import MLResult, factorize, likelihood, nmf_update  # noqa: F401
+
 __version__ = "0.1.0"

@@ -83,6 +83,14 @@ SIGNATURES = {
                            + [_D] * 5 + [c_double_p] * 7),
     "vbnmf_update_csc": (ctypes.c_int, [_I64, _I64, _I32, c_int32_p, c_int32_p, c_double_p,
                                         c_double_p, c_double_p, c_double_p] + [_D] * 5 + [c_double_p] * 7),
+    "vbnmf_engine_ml_set_state": (ctypes.c_int, [_VP, c_double_p, c_double_p]),
+    "vbnmf_engine_ml_step": (ctypes.c_int, [_VP, _I32, _D, _D, c_double_p]),
+    "vbnmf_engine_ml_likelihood": (ctypes.c_int, [_VP, c_double_p]),
+    "vbnmf_engine_ml_get_state": (ctypes.c_int, [_VP, c_double_p, c_double_p]),
+    "vbnmf_ml_update_dense": (ctypes.c_int, [_I64, _I64, _I32, c_double_p, c_double_p, c_double_p, _I32, _D, _D,
+                                             c_double_p, c_double_p, c_double_p]),
+    "vbnmf_ml_update_csc": (ctypes.c_int, [_I64, _I64, _I32, c_int32_p, c_int32_p, c_double_p, c_double_p, c_double_p,
+                                           _I32, _D, _D, c_double_p, c_double_p, c_double_p]),
     "vbnmf_layout_build": (ctypes.c_int, [_VP, _I64, _I64, _I32, _I32, _VPP, ctypes.POINTER(LayoutView)]),
     "vbnmf_layout_destroy": (None, [_VP]),
     "vbnmf_test_special_host": (ctypes.c_int, [_I32, _I64, c_double_p, c_double_p]),

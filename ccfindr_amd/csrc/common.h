@@ -33,6 +33,8 @@ struct Matrix {
 
 // sum over stored entries of lgamma(x+1) for columns [cb, ce), fixed summation order.
 double sum_lgamma_x1(const Matrix &X, int64_t cb, int64_t ce);
+// sum over stored entries of -x log x + x (the constant of the ML-NMF likelihood, reference R/factorize.R:46-47).
+double sum_xlogx(const Matrix &X, int64_t cb, int64_t ce);
 
 // ---- tiled device layout of one side (DESIGN.md "Data layout in HBM") ----
 //

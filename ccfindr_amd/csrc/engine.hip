@@ -18,6 +18,7 @@
 
 #include "common.h"
 #include "kernels.h"
+#include "mlnmf.h"
 
 using namespace vbnmf;
 
@@ -70,6 +71,7 @@ struct vbnmf_engine {
     int r = 0, R = 0, NT = 0, n_wg = 0;
     bool wide = false, partitioned = false;
     double lgx = 0.0;
+    double xlx = 0.0;                 // sum over stored entries of -x log x + x (ML-NMF likelihood constant)
     DeviceSide A, B;                  // A: lanes own genes ; B: lanes own cells
     double *lw = nullptr, *llw = nullptr, *ew = nullptr, *dw = nullptr;
     double *lh = nullptr, *llh = nullptr, *eh = nullptr, *dh = nullptr;
@@ -88,9 +90,10 @@ struct vbnmf_engine {
     size_t dbg_count = 0;
     size_t lds_bytes = 0;
     bool has_state = false, stats_ready = false, step_pending = false, prime_pending = false;
+    bool ml_ready = false;            // lw / lh hold an ML-NMF state (w, h) and the cell-side statistics are current
     bool timing = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool ev_recorded = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+    bool ev_recorded = false, ev2_recorded = false;
     double sweep_ms = 0.0;
     int64_t sweep_launches = 0;
 };
@@ -263,6 +266,80 @@ int launch_pack(vbnmf_engine *e)
     return VBNMF_OK;
 }
 
+// ---- ML-NMF (mlnmf.h): single-side sweeps and the multiplicative updates ----
+template <int R, bool WIDE, bool LOGTERM, int NT>
+int launch_sweep1_t(vbnmf_engine *e, const SweepSide &a)
+{
+    static bool attr_set[16] = {false};
+    const void *fn = (const void *)k_sweep1<R, WIDE, LOGTERM, NT>;
+    if (e->device >= 16 || !attr_set[e->device]) {
+        HIPCHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        if (e->device < 16) attr_set[e->device] = true;
+    }
+    hipLaunchKernelGGL((k_sweep1<R, WIDE, LOGTERM, NT>), dim3((unsigned)e->n_wg), dim3(NT), e->lds_bytes, e->stream, a);
+    HIPCHECK(hipGetLastError());
+    return VBNMF_OK;
+}
+
+template <int R>
+int launch_sweep1_r(vbnmf_engine *e, const SweepSide &a, bool logterm)
+{
+    constexpr int NT = sweep_threads(R);
+    if (e->wide) return logterm ? launch_sweep1_t<R, true, true, NT>(e, a) : launch_sweep1_t<R, true, false, NT>(e, a);
+    return logterm ? launch_sweep1_t<R, false, true, NT>(e, a) : launch_sweep1_t<R, false, false, NT>(e, a);
+}
+
+// gene side: lanes own genes (F = w, G = h), statistics for the W update; cell side: F = h, G = w, statistics
+// for the H update and sum x log(wh) in the cell half of epart.
+int launch_sweep1(vbnmf_engine *e, bool gene_side)
+{
+    SweepSide a = sweep_side_args(e, gene_side ? e->A : e->B, gene_side, gene_side ? e->epart : e->epart + e->n_wg);
+    a.logterm = gene_side ? 0 : 1;
+    a.stop = nullptr;
+    hipEvent_t t0 = gene_side ? e->ev0 : e->ev2, t1 = gene_side ? e->ev1 : e->ev3;
+    if (e->timing) { HIPCHECK(hipEventRecord(t0, e->stream)); }
+    int rc = VBNMF_ERR_BAD_ARG;
+    switch (e->R) {
+#define X(RR) case RR: rc = launch_sweep1_r<RR>(e, a, !gene_side); break;
+        VBNMF_FOR_EACH_R(X)
+#undef X
+        default: return fail(VBNMF_ERR_BAD_ARG, "unsupported padded rank %d", e->R);
+    }
+    if (rc) return rc;
+    if (e->timing) { HIPCHECK(hipEventRecord(t1, e->stream)); (gene_side ? e->ev_recorded : e->ev2_recorded) = true; }
+    return VBNMF_OK;
+}
+
+int launch_ml_update(vbnmf_engine *e, bool gene_side, int prior, double ga, double gb, double eps)
+{
+    const DeviceSide &S = gene_side ? e->A : e->B;
+    const int64_t nmaj = gene_side ? e->n : e->m;
+    const double *other_bp = gene_side ? e->bpH : e->bpW;
+    double *f = gene_side ? e->lw : e->lh;
+    double *bp = gene_side ? e->bpW : e->bpH;
+    switch (e->R) {
+#define X(RR) case RR: hipLaunchKernelGGL((k_ml_update<RR>), dim3(kUpdateBlocks), dim3(kUpdateThreads), 0, e->stream, S.part, S.inv_ptr, S.inv_task, nmaj, e->r, other_bp, kUpdateBlocks, prior, ga, gb, eps, f, bp); break;
+        VBNMF_FOR_EACH_R(X)
+#undef X
+        default: return fail(VBNMF_ERR_BAD_ARG, "unsupported padded rank %d", e->R);
+    }
+    HIPCHECK(hipGetLastError());
+    return VBNMF_OK;
+}
+
+int launch_ml_final(vbnmf_engine *e)
+{
+    e->seq += 1.0;
+    switch (e->R) {
+#define X(RR) case RR: hipLaunchKernelGGL((k_ml_final<RR>), dim3(1), dim3(1024), 0, e->stream, e->bpW, e->bpH, kUpdateBlocks, e->epart + e->n_wg, (int64_t)e->n_wg, e->xlx, e->r, (double)e->n, (double)e->m, e->seq, e->d_out, e->h_out_dev); break;
+        VBNMF_FOR_EACH_R(X)
+#undef X
+        default: return fail(VBNMF_ERR_BAD_ARG, "unsupported padded rank %d", e->R);
+    }
+    HIPCHECK(hipGetLastError());
+    return VBNMF_OK;
+}
+
 // Wait for k_final's sequence flag in pinned memory; falls back to the stream if it takes long.
 int wait_result(vbnmf_engine *e)
 {
@@ -291,6 +368,14 @@ int harvest_timing(vbnmf_engine *e)
         e->sweep_ms += ms;
         e->sweep_launches++;
         e->ev_recorded = false;
+    }
+    if (e->timing && e->ev2_recorded) {
+        float ms = 0.f;
+        HIPCHECK(hipEventSynchronize(e->ev3));
+        HIPCHECK(hipEventElapsedTime(&ms, e->ev2, e->ev3));
+        e->sweep_ms += ms;
+        e->sweep_launches++;
+        e->ev2_recorded = false;
     }
     return VBNMF_OK;
 }
@@ -342,6 +427,8 @@ void vbnmf_engine_destroy(vbnmf_engine *e)
     if (e->h_out) (void)hipHostFree(e->h_out);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
+    if (e->ev2) (void)hipEventDestroy(e->ev2);
+    if (e->ev3) (void)hipEventDestroy(e->ev3);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -391,6 +478,7 @@ int vbnmf_engine_create_part(const vbnmf_matrix *X, int64_t cb, int64_t ce, int6
     }
     if (rc) return bail(rc);
     e->lgx = (cb == 0 && ce == X->M.m) ? X->lgx : sum_lgamma_x1(X->M, cb, ce);
+    e->xlx = sum_xlogx(X->M, cb, ce);
     static_assert(kLdsRowBase == kLdsReserveBytes, "host and device disagree on the sweep's LDS reserve");
     e->lds_bytes = kLdsRowBase + (size_t)std::max(e->A.block_width, e->B.block_width) * lds_row_bytes(e->R);
     {
@@ -413,7 +501,8 @@ int vbnmf_engine_create_part(const vbnmf_matrix *X, int64_t cb, int64_t ce, int6
     if ((he = hipHostMalloc((void **)&e->h_out, 8 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess ||
         (he = hipHostGetDevicePointer((void **)&e->h_out_dev, e->h_out, 0)) != hipSuccess ||
         (he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)) != hipSuccess ||
-        (he = hipEventCreate(&e->ev0)) != hipSuccess || (he = hipEventCreate(&e->ev1)) != hipSuccess)
+        (he = hipEventCreate(&e->ev0)) != hipSuccess || (he = hipEventCreate(&e->ev1)) != hipSuccess ||
+        (he = hipEventCreate(&e->ev2)) != hipSuccess || (he = hipEventCreate(&e->ev3)) != hipSuccess)
         return bail(fail(VBNMF_ERR_HIP, "engine setup failed: %s", hipGetErrorString(he)));
     e->own_stream = true;
     std::memset(e->h_out, 0, 8 * sizeof(double));
@@ -488,6 +577,7 @@ int vbnmf_engine_set_state(vbnmf_engine *e, const double *lw, const double *lh, 
     if (!e || !lw || !lh || !eh) return fail(VBNMF_ERR_BAD_ARG, "NULL argument");
     if (int rc = use_device(e)) return rc;
     e->has_state = false; e->stats_ready = false; e->step_pending = false; e->prime_pending = false;
+    e->ml_ready = false;
     try {
         std::vector<double> tmp;
         to_index_major(lw, e->n, e->r, e->R, false, tmp);
@@ -675,7 +765,7 @@ int vbnmf_engine_timing_enable(vbnmf_engine *e, int32_t on)
 {
     if (!e) return fail(VBNMF_ERR_BAD_ARG, "engine handle is NULL");
     e->timing = on != 0;
-    e->sweep_ms = 0.0; e->sweep_launches = 0; e->ev_recorded = false;
+    e->sweep_ms = 0.0; e->sweep_launches = 0; e->ev_recorded = false; e->ev2_recorded = false;
     return VBNMF_OK;
 }
 
@@ -714,6 +804,99 @@ int vbnmf_engine_debug_times(vbnmf_engine *e, unsigned long long *out, int64_t c
         if (int rc = use_device(e)) return rc;
         HIPCHECK(hipStreamSynchronize(e->stream));
         HIPCHECK(hipMemcpy(out, e->dbg, e->dbg_count * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    }
+    return VBNMF_OK;
+}
+
+// ---------------------------------------------------------------- ML-NMF on the same engine
+// (reference R/factorize.R:2-27 nmf_updateR, :40-49 likelihood; the factors live in the lw / lh arrays)
+int vbnmf_engine_ml_set_state(vbnmf_engine *e, const double *w, const double *h)
+{
+    if (!e || !w || !h) return fail(VBNMF_ERR_BAD_ARG, "NULL argument");
+    if (e->partitioned) return fail(VBNMF_ERR_STATE, "ML-NMF needs an unpartitioned engine");
+    if (int rc = use_device(e)) return rc;
+    e->has_state = false; e->stats_ready = false; e->step_pending = false; e->prime_pending = false; e->ml_ready = false;
+    try {
+        std::vector<double> tmp;
+        to_index_major(w, e->n, e->r, e->R, false, tmp);
+        HIPCHECK(hipMemcpyAsync(e->lw, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
+        HIPCHECK(hipStreamSynchronize(e->stream));
+        to_index_major(h, e->m, e->r, e->R, true, tmp);
+        HIPCHECK(hipMemcpyAsync(e->lh, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
+        HIPCHECK(hipStreamSynchronize(e->stream));
+    } catch (const std::bad_alloc &) {
+        return fail(VBNMF_ERR_OOM, "out of host memory staging the state");
+    }
+    // colSums(w) block partials, then the cell-side statistics the first H update starts from
+    switch (e->R) {
+#define X(RR) case RR: hipLaunchKernelGGL((k_prime<RR>), dim3(kUpdateBlocks), dim3(kUpdateThreads), 0, e->stream, e->n, e->r, e->lw, e->llw, e->lw, e->bpW); break;
+        VBNMF_FOR_EACH_R(X)
+#undef X
+        default: return fail(VBNMF_ERR_BAD_ARG, "unsupported padded rank %d", e->R);
+    }
+    HIPCHECK(hipGetLastError());
+    switch (e->R) {                                  // rowSums(h) block partials, for the likelihood of the loaded pair
+#define X(RR) case RR: hipLaunchKernelGGL((k_prime<RR>), dim3(kUpdateBlocks), dim3(kUpdateThreads), 0, e->stream, e->m, e->r, e->lh, e->llh, e->lh, e->bpH); break;
+        VBNMF_FOR_EACH_R(X)
+#undef X
+    }
+    HIPCHECK(hipGetLastError());
+    const bool timing = e->timing;
+    e->timing = false;                               // the priming sweep is not a step
+    int rc = launch_sweep1(e, false);
+    e->timing = timing;
+    if (rc) return rc;
+    if ((rc = launch_ml_final(e))) return rc;
+    if ((rc = wait_result(e))) return rc;
+    e->ml_ready = true;
+    return VBNMF_OK;
+}
+
+int vbnmf_engine_ml_likelihood(vbnmf_engine *e, double *lk)
+{
+    if (!e || !lk) return fail(VBNMF_ERR_BAD_ARG, "NULL argument");
+    if (!e->ml_ready) return fail(VBNMF_ERR_STATE, "ml_likelihood before ml_set_state");
+    *lk = e->h_out[0];                               // left there by the last k_ml_final (set_state or step)
+    return VBNMF_OK;
+}
+
+int vbnmf_engine_ml_step(vbnmf_engine *e, int32_t prior, double gamma_a, double gamma_b, double *lk)
+{
+    if (!e) return fail(VBNMF_ERR_BAD_ARG, "engine handle is NULL");
+    if (!e->ml_ready) return fail(VBNMF_ERR_STATE, "ml_step before ml_set_state");
+    if (int rc = use_device(e)) return rc;
+    const double eps = 2.220446049250313e-16;        // .Machine$double.eps (R/factorize.R:15,24)
+    if (int rc = launch_ml_update(e, false, prior, gamma_a, gamma_b, eps)) return rc;   // H first (:8-15)
+    if (int rc = launch_sweep1(e, true)) return rc;
+    if (int rc = launch_ml_update(e, true, prior, gamma_a, gamma_b, eps)) return rc;    // then W on the new h (:17-24)
+    if (int rc = launch_sweep1(e, false)) return rc;
+    if (int rc = launch_ml_final(e)) return rc;
+    if (int rc = wait_result(e)) return rc;
+    if (int rc = harvest_timing(e)) return rc;
+    if (lk) *lk = e->h_out[0];
+    return VBNMF_OK;
+}
+
+int vbnmf_engine_ml_get_state(vbnmf_engine *e, double *w, double *h)
+{
+    if (!e) return fail(VBNMF_ERR_BAD_ARG, "engine handle is NULL");
+    if (!e->ml_ready) return fail(VBNMF_ERR_STATE, "ml_get_state before ml_set_state");
+    if (int rc = use_device(e)) return rc;
+    HIPCHECK(hipStreamSynchronize(e->stream));
+    try {
+        std::vector<double> tmp;
+        if (w) {
+            tmp.resize((size_t)e->n * e->R);
+            HIPCHECK(hipMemcpy(tmp.data(), e->lw, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+            from_index_major(tmp, e->n, e->r, e->R, false, w);
+        }
+        if (h) {
+            tmp.resize((size_t)e->m * e->R);
+            HIPCHECK(hipMemcpy(tmp.data(), e->lh, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+            from_index_major(tmp, e->m, e->r, e->R, true, h);
+        }
+    } catch (const std::bad_alloc &) {
+        return fail(VBNMF_ERR_OOM, "out of host memory staging the state");
     }
     return VBNMF_OK;
 }
@@ -793,6 +976,38 @@ int vbnmf_update_csc(int64_t n, int64_t m, int32_t r, const int32_t *p, const in
     vbnmf_matrix *M = nullptr;
     if (int rc = vbnmf_matrix_from_csc(n, m, p, i, x, &M)) return rc;
     return update_once(M, r, lw_in, lh_in, eh_in, aw, bw, ah, bh, fudge, lw, lh, ew, eh, dw, dh, lkh);
+}
+
+static int ml_update_once(vbnmf_matrix *X, int32_t r, const double *w_in, const double *h_in, int32_t prior,
+                          double gamma_a, double gamma_b, double *w, double *h, double *lk)
+{
+    vbnmf_engine *e = nullptr;
+    int rc = vbnmf_engine_create(X, r, 0, &e);
+    if (!rc) rc = vbnmf_engine_ml_set_state(e, w_in, h_in);
+    if (!rc) rc = vbnmf_engine_ml_step(e, prior, gamma_a, gamma_b, lk);
+    if (!rc) rc = vbnmf_engine_ml_get_state(e, w, h);
+    vbnmf_engine_destroy(e);
+    vbnmf_matrix_destroy(X);
+    return rc;
+}
+
+int vbnmf_ml_update_dense(int64_t n, int64_t m, int32_t r, const double *X, const double *w_in, const double *h_in,
+                          int32_t prior, double gamma_a, double gamma_b, double *w, double *h, double *lk)
+{
+    if (!w_in || !h_in) return fail(VBNMF_ERR_BAD_ARG, "w or h is NULL");
+    vbnmf_matrix *M = nullptr;
+    if (int rc = vbnmf_matrix_from_dense(n, m, X, &M)) return rc;
+    return ml_update_once(M, r, w_in, h_in, prior, gamma_a, gamma_b, w, h, lk);
+}
+
+int vbnmf_ml_update_csc(int64_t n, int64_t m, int32_t r, const int32_t *p, const int32_t *i, const double *x,
+                        const double *w_in, const double *h_in, int32_t prior, double gamma_a, double gamma_b,
+                        double *w, double *h, double *lk)
+{
+    if (!w_in || !h_in) return fail(VBNMF_ERR_BAD_ARG, "w or h is NULL");
+    vbnmf_matrix *M = nullptr;
+    if (int rc = vbnmf_matrix_from_csc(n, m, p, i, x, &M)) return rc;
+    return ml_update_once(M, r, w_in, h_in, prior, gamma_a, gamma_b, w, h, lk);
 }
 
 }  // extern "C"

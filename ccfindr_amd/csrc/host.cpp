@@ -235,6 +235,33 @@ double sum_lgamma_x1(const Matrix &X, int64_t cb, int64_t ce)
     return s;
 }
 
+// sum over stored entries of -x log x + x (reference R/factorize.R:46-47), columns [cb, ce), fixed order.
+double sum_xlogx(const Matrix &X, int64_t cb, int64_t ce)
+{
+    std::vector<double> table;
+    if (X.counts_u16) {
+        double mx = 0;
+        for (int64_t e = X.colptr[cb]; e < X.colptr[ce]; e++) mx = std::max(mx, X.val[e]);
+        table.resize((size_t)mx + 1);
+        table[0] = 0.0;
+        for (size_t c = 1; c < table.size(); c++) table[c] = -(double)c * std::log((double)c) + (double)c;
+    }
+    std::vector<double> colsum(ce - cb, 0.0);
+    parallel_for(ce - cb, [&](int64_t b, int64_t e, int) {
+        for (int64_t j = b; j < e; j++) {
+            double s = 0.0;
+            for (int64_t q = X.colptr[cb + j]; q < X.colptr[cb + j + 1]; q++) {
+                const double v = X.val[q];
+                s += X.counts_u16 ? table[(size_t)v] : (v > 0.0 ? -v * std::log(v) + v : 0.0);
+            }
+            colsum[j] = s;
+        }
+    });
+    double s = 0.0;
+    for (double v : colsum) s += v;
+    return s;
+}
+
 // ------------------------------------------------------------------ layout
 static int env_int(const char *name, int dflt)
 {

@@ -153,7 +153,9 @@ __device__ __attribute__((noinline)) int take_ticket(int *ticket)
     return __shfl(i, 0, 64);
 }
 
-template <int R, bool WIDE, bool LOGTERM, int NT>
+// EV selects the per-slice scalar left in the evidence slots: 1 = the VB data term sum(acc . llF) - sum x log(wth)
+// (see the header), 2 = sum x log(wth) alone (ML-NMF likelihood, mlnmf.h), 0 = nothing.
+template <int R, bool WIDE, bool LOGTERM, int NT, int EV = 1>
 __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restrict__ ldsG)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -283,7 +285,7 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
 #pragma unroll
                 for (int kk = 0; kk < R / 2; kk++) P[kk] = make_double2(T.acc[2 * kk], T.acc[2 * kk + 1]);
             }
-            if (M != kIdle) {
+            if (EV == 1 && M != kIdle) {
                 const double2 *L2 = reinterpret_cast<const double2 *>(S.llF + (size_t)M * R);
 #pragma unroll
                 for (int kk = 0; kk < R / 2; kk++) {
@@ -293,6 +295,7 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
                 }
                 ev -= T.lsum;
             }
+            if (EV == 2 && M != kIdle) ev = T.lsum;
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) ev += __shfl_down(ev, d, 64);
             if (lane == 0) ev_slot[i] = ev;                // this slice's evidence partial
@@ -324,6 +327,15 @@ __global__ __launch_bounds__(NT) void k_sweep(const SweepSide A, const SweepSide
     if (A.stop && *A.stop) return;               // the driver loop has ended: leave the statistics as they are
     sweep_side<R, WIDE, true, NT>(A, ldsG);      // lanes own genes: statistics sw + the sum x log(wth)
     sweep_side<R, WIDE, false, NT>(B, ldsG);     // lanes own cells: statistics sh
+}
+
+// One side alone (ML-NMF: its H and W updates are sequential, reference R/factorize.R:8-24, so each needs its
+// own pass over X; the cell-side pass also yields the likelihood's sum x log(wh)).
+template <int R, bool WIDE, bool LOGTERM, int NT>
+__global__ __launch_bounds__(NT) void k_sweep1(const SweepSide S)
+{
+    extern __shared__ double2 ldsG[];
+    sweep_side<R, WIDE, LOGTERM, NT, LOGTERM ? 2 : 0>(S, ldsG);
 }
 
 // Sum of one major's task partials for column k, in the inverse index's fixed order.  The

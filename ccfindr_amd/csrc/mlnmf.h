@@ -1,0 +1,91 @@
+// mlnmf.h -- gfx950 kernels of the maximum-likelihood NMF step (included once, by engine.hip, after kernels.h).
+//
+// Reference: R/factorize.R:2-27 (nmf_updateR) and :40-49 (likelihood), behind factorize() (:140-320).
+//   :8-15   h <- h .* (t(w) %*% (x / (w %*% h))) / colSums(w)   [+ Gamma prior: up + a - 1, down + a/b] ; clip at eps
+//   :17-24  w <- w .* ((x / (w %*% h_new)) %*% t(h_new)) / rowSums(h_new)                               ; clip at eps
+//   :40-49  lk = ( sum(x log(wh) - wh) + sum_{x>0}(-x log x + x) ) / n / m    on the NEW w, h
+// The two updates are sequential (the W update sees the new h), so a step makes two single-side sweeps over
+// X (k_sweep1 in kernels.h, same tiled layout and per-task partials as the VB sweep):
+//   k_ml_update(H) -> k_sweep1(gene side: w, h_new) -> k_ml_update(W) -> k_sweep1(cell side: h_new, w_new) -> k_ml_final
+// The cell-side sweep at the END of step t runs on (w_new, h_new): it yields the statistics the H update of
+// step t+1 starts from AND sum x log(wh) of step t's likelihood; sum(wh) = sum_k colSum(w)_k rowSum(h)_k comes
+// from the updates' block partials, and sum_{x>0}(-x log x + x) is a constant of X computed once at ingestion.
+#pragma once
+#include "kernels.h"
+
+namespace vbnmf {
+
+// One factor's multiplicative update.  Thread (row_sub, k) walks its block's majors with a fixed k:
+//   s    = sum of the major's task partials (fixed order)          = (t(w) %*% (x/wh))[k, major] or its W twin
+//   up   = f * s [+ a - 1] ; down = colsum_other[k] [+ a/b] ; f <- max(up / down, eps)   (NaN stays NaN, as in R)
+// other_bp[other_nb][R+2] are the OTHER factor's block partials of its column sums; this factor's go to bp.
+template <int R>
+__global__ __launch_bounds__(kUpdateThreads) void k_ml_update(
+    const double *__restrict__ part, const int32_t *__restrict__ inv_ptr, const uint32_t *__restrict__ inv_task,
+    int64_t nmaj, int r, const double *__restrict__ other_bp, int other_nb, int prior, double ga, double gb, double eps,
+    double *__restrict__ f, double *__restrict__ bp)
+{
+    constexpr int RB = kUpdateThreads / R;       // majors per pass
+    __shared__ double s_other[R + 2];
+    __shared__ double s_e[kUpdateThreads];
+    const int t = threadIdx.x;
+    bp_colsums(other_bp, other_nb, R + 2, s_other, kUpdateThreads);
+    __syncthreads();
+
+    const int row = t / R, k = t - row * R;
+    const int64_t per = (nmaj + gridDim.x - 1) / gridDim.x;
+    const int64_t m0 = (int64_t)blockIdx.x * per, m1 = min(nmaj, m0 + per);
+    double down = s_other[k < R ? k : 0];
+    if (prior) down = down + ga / gb;            // R/factorize.R:12,21
+    double ve = 0.0;
+    if (row < RB) {
+        for (int64_t M = m0 + row; M < m1; M += RB) {
+            const size_t o = (size_t)M * R + k;
+            if (k < r) {
+                const double s = task_sum(part, inv_task, inv_ptr[M], inv_ptr[M + 1], R, k);
+                double up = f[o] * s;
+                if (prior) up = up + ga - 1.0;   // :11,20
+                double v = up / down;
+                if (v < eps) v = eps;            // :15,24
+                f[o] = v;
+                ve += v;
+            } else {
+                f[o] = 0.0;
+            }
+        }
+    }
+    s_e[t] = ve;
+    __syncthreads();
+    constexpr int P2 = (RB <= 32) ? 32 : (RB <= 64) ? 64 : (RB <= 128) ? 128 : (RB <= 256) ? 256 : 512;
+    for (int h = P2 / 2; h >= 1; h >>= 1) {
+        if (row < h && row + h < RB) s_e[t] += s_e[t + h * R];
+        __syncthreads();
+    }
+    double *o = bp + (size_t)blockIdx.x * (R + 2);
+    if (t < R) o[t] = s_e[t];
+    if (t == 0) { o[R] = 0.0; o[R + 1] = 0.0; }
+}
+
+// Likelihood (R/factorize.R:40-49).  One block.  out = [lk, sum x log(wh), sum(wh), 0, 0], out_host[7] = seq.
+template <int R>
+__global__ __launch_bounds__(1024) void k_ml_final(const double *__restrict__ bpW, const double *__restrict__ bpH, int nb,
+                                                   const double *__restrict__ epart, int64_t nepart, double xlx, int r,
+                                                   double n, double m, double seq, double *__restrict__ out,
+                                                   double *__restrict__ out_host)
+{
+    __shared__ double sW[R + 2], sH[R + 2];
+    __shared__ double sm[1024];
+    bp_colsums(bpW, nb, R + 2, sW, 1024);
+    bp_colsums(bpH, nb, R + 2, sH, 1024);
+    const double data = block_vec_sum(epart, nepart, sm);
+    if (threadIdx.x == 0) {
+        double cross = 0.0;
+        for (int k = 0; k < r; k++) cross += sW[k] * sH[k];
+        double o[5] = {((data - cross) + xlx) / n / m, data, cross, 0.0, 0.0};
+        for (int q = 0; q < 5; q++) { out[q] = o[q]; out_host[q] = o[q]; }
+        __threadfence_system();
+        reinterpret_cast<volatile double *>(out_host)[7] = seq;
+    }
+}
+
+}  // namespace vbnmf

@@ -147,6 +147,31 @@ class VBEngine:
                                             ctypes.byref(lkh), st))
         return lkh.value, tuple(st)
 
+    # -- maximum-likelihood NMF on the same engine (reference R/factorize.R:2-27, :40-49) ----
+    def ml_set_state(self, w, h):
+        w, h = N.fcol(w), N.fcol(h)
+        if w.shape != (self.n, self.rank) or h.shape != (self.rank, self.m):
+            raise ValueError(f"state shapes must be w {(self.n, self.rank)}, h {(self.rank, self.m)}")
+        N.check(self._lib.vbnmf_engine_ml_set_state(self._h, N.dptr(w), N.dptr(h)))
+
+    def ml_step(self, prior=False, gamma_a=1.0, gamma_b=1.0):
+        """One nmf_updateR step on the resident (w, h) -> likelihood of the updated pair."""
+        lk = ctypes.c_double()
+        N.check(self._lib.vbnmf_engine_ml_step(self._h, int(bool(prior)), float(gamma_a), float(gamma_b), ctypes.byref(lk)))
+        return lk.value
+
+    def ml_likelihood(self):
+        """likelihood(mat, w, h) of the pair the engine holds now."""
+        lk = ctypes.c_double()
+        N.check(self._lib.vbnmf_engine_ml_likelihood(self._h, ctypes.byref(lk)))
+        return lk.value
+
+    def ml_get_state(self, names=("ew", "eh")):
+        w = np.empty((self.n, self.rank), order="F") if "ew" in names else None
+        h = np.empty((self.rank, self.m), order="F") if "eh" in names else None
+        N.check(self._lib.vbnmf_engine_ml_get_state(self._h, N.dptr(w), N.dptr(h)))
+        return {k: v for k, v in (("ew", w), ("eh", h)) if v is not None}
+
     def run(self, hyper, Itmax=10000, Tol=1e-5, n0=10, dn=1, flags=(True,) * 4, fudge=EPS, history=False):
         """The per-rank loop of vb_iterate (reference R/bayesian.R:336-352) driven by the device.
 

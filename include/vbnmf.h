@@ -191,6 +191,38 @@ int vbnmf_update_csc(int64_t n, int64_t m, int32_t r, const int32_t *p, const in
                      double *dw, double *dh, double *lkh);
 
 /* ---------------------------------------------------------------------------------
+ * Maximum-likelihood NMF on the same engine: the step of
+ * factorize(), reference R/factorize.R:2-27 (nmf_updateR) with its likelihood :40-49
+ * (the two are always called together, :195-196).  The factors live on the device
+ * between steps; a VB state and an ML state exclude each other (setting one drops the
+ * other).  Unpartitioned engines only.
+ *
+ *   ml_set_state  w : n x r column-major, h : r x m column-major (init, :30-38)
+ *   ml_step       h <- h .* (t(w) %*% (x/(w h))) / colSums(w), clipped at double eps (:8-15);
+ *                 then w <- w .* ((x/(w h)) %*% t(h)) / rowSums(h) on the NEW h (:17-24);
+ *                 prior != 0 adds the Gamma prior terms (up + gamma_a - 1, down +
+ *                 gamma_a/gamma_b, :10-13,19-22; factorize() itself never sets it).
+ *                 *lk = likelihood(mat, w, h) of the updated pair (:40-49).
+ *   ml_likelihood likelihood(mat, w, h) (:40-49) of the pair the engine holds now (after
+ *                 ml_set_state: of the loaded pair; after ml_step: the value ml_step returned).
+ *   ml_get_state  the current w, h (either may be NULL).
+ * --------------------------------------------------------------------------------- */
+int vbnmf_engine_ml_set_state(vbnmf_engine *e, const double *w, const double *h);
+int vbnmf_engine_ml_step(vbnmf_engine *e, int32_t prior, double gamma_a, double gamma_b, double *lk);
+int vbnmf_engine_ml_likelihood(vbnmf_engine *e, double *lk);
+int vbnmf_engine_ml_get_state(vbnmf_engine *e, double *w, double *h);
+/* Stateless forms of the same step: nmf_updateR(x, w, h, n, m, r, prior, gamma.a, gamma.b)
+ * followed by likelihood(x, w, h) (R/factorize.R:2-27, :40-49); throw-away engine on device 0. */
+int vbnmf_ml_update_dense(int64_t n, int64_t m, int32_t r, const double *X,
+                          const double *w_in, const double *h_in,
+                          int32_t prior, double gamma_a, double gamma_b,
+                          double *w, double *h, double *lk);
+int vbnmf_ml_update_csc(int64_t n, int64_t m, int32_t r, const int32_t *p, const int32_t *i,
+                        const double *x, const double *w_in, const double *h_in,
+                        int32_t prior, double gamma_a, double gamma_b,
+                        double *w, double *h, double *lk);
+
+/* ---------------------------------------------------------------------------------
  * Host-only inspection of the tiled device layout (no GPU needed): builds the layout
  * for one side at padded rank r and hands out its arrays so tests can check, bit for
  * bit, that the slices hold exactly X.  side 0 = gene side (lanes own genes, minor =
