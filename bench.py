@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--small", action="store_true", help="2k x 5k smoke-sized workload (not the headline)")
     ap.add_argument("--cpu-steps", type=int, default=4)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-ml", action="store_true", help="skip the ML-NMF side measurement")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -176,6 +177,45 @@ def main():
         dev_loop = {"value": res["it"] / dt_dev, "unit": "iterations/s", "ms_per_step": 1e3 * dt_dev / max(res["it"], 1),
                     "steps": res["it"], "lkh_last": res["lkh"]}
 
+    # The maximum-likelihood NMF step of factorize() (reference R/factorize.R:2-27 + :40-49)
+    # on the same matrix and rank: K steps, host-stepped, reported beside the headline (never part of `value`).
+    ml = None
+    if world == 1 and hasattr(eng, "ml_step") and not args.no_ml:
+        rng = np.random.default_rng(2003)
+        w_ml, h_ml = rng.uniform(size=(n, r)), rng.uniform(size=(r, m))
+        eng.ml_set_state(w_ml, h_ml)
+        ml_lk = [eng.ml_step() for _ in range(max(args.warmup, 2))]
+        base_eng.timing_enable(True)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for _ in range(args.steps):
+            lk_ml = eng.ml_step()
+        torch.cuda.synchronize()
+        dt_ml = time.perf_counter() - t2
+        ml_ms, ml_cnt = base_eng.timing_get()
+        base_eng.timing_enable(False)
+        x_pass = 12 * nnz + 4 * (n + 1)
+        ml_bytes = 2 * x_pass + 24 * (n * r + r * m)       # two passes over X (H then W), factors read twice, statistics written once
+        ml = {"value": args.steps / dt_ml, "unit": "iterations/s", "ms_per_step": 1e3 * dt_ml / args.steps, "steps": args.steps,
+              "lk_last": lk_ml, "sweeps_ms_per_step": 2.0 * ml_ms / max(ml_cnt, 1),
+              "roofline": {"bound": "hbm", "kernel": "k_sweep1 x2", "algorithmic_bytes_per_step": ml_bytes,
+                           "achieved": ml_bytes / (2.0 * ml_ms / max(ml_cnt, 1) * 1e-3) / 1e9 if ml_cnt else None,
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": ml_bytes / (2.0 * ml_ms / max(ml_cnt, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS if ml_cnt else None}}
+        if not args.no_cpu:
+            from oracle import mlnmf_oracle as OM
+            cores = usable_cores()
+            S = X.tocsc()
+            t3 = time.perf_counter()
+            w_c, h_c, cpu_lk = w_ml, h_ml, []
+            for _ in range(2):
+                o = OM.update_csc(n, m, S.indptr, S.indices, S.data, w_c, h_c, nthreads=cores)
+                w_c, h_c = o["ew"], o["eh"]
+                cpu_lk.append(o["lk"])
+            ml["cpu_baseline"] = {"value": 2 / (time.perf_counter() - t3), "unit": "iterations/s", "cores": cores, "kind": "port",
+                                  "sample": f"2 full steps of the same workload (oracle mlnmf update_csc, OpenMP x{cores})"}
+            ml["lk_rel_err_first_steps"] = max(abs(g / c - 1) for g, c in zip(ml_lk[:2], cpu_lk))
+
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -215,6 +255,8 @@ def main():
         }
         if dev_loop:
             out["device_loop"] = dev_loop
+        if ml:
+            out["ml_nmf"] = ml
         if not args.no_cpu and world == 1:
             wh_cpu = synth.random_state(n, m, r, HYPER, seed=1003)
             cb, cpu_lk = cpu_baseline(X, r, wh_cpu, ncheck)

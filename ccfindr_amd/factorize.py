@@ -137,6 +137,7 @@ def factorize(mat, ranks=2, nrun=20, randomize=False, nsmpl=1, verbose=2, progre
     else:
         M = CountMatrix(mat)
         host = mat
+        M.host = mat                    # what the matrix was built from (engine factories of the CPU tests read it)
     er, ec = M.empty_counts()
     if er > 0:
         raise ValueError("Input matrix contains empty rows")                       # :151
@@ -169,6 +170,7 @@ def factorize(mat, ranks=2, nrun=20, randomize=False, nsmpl=1, verbose=2, progre
                 A = np.array(host.toarray() if hasattr(host, "toarray") else host, dtype=np.float64)
                 A = np.apply_along_axis(rng.permutation, 0, A)
                 Ms = CountMatrix(A)
+                Ms.host = A
             else:
                 Ms = M
             eng = engine_factory(Ms, rank) if engine_factory else VBEngine(Ms, rank, device=device)

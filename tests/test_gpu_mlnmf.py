@@ -183,3 +183,85 @@ def test_factorize_matches_oracle_loop():
         assert relerr(res.basis[irank], best["ew"]) <= 1e-7 and relerr(res.coeff[irank], best["eh"]) <= 1e-7
         assert abs(res.measure["dispersion"][irank] - O.dispersion(conav / 3, 110)) <= 1e-12
         assert abs(res.measure["cophenetic"][irank] - O.cophenet(conav / 3, 110)) <= 1e-9
+
+
+# ---- committed golden vectors (tests/golden/ml_*.npz, tests/golden/make_golden_ml.py) ----
+import glob
+import os
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "ml_step_*.npz"))), ids=lambda p: os.path.basename(p)[8:-4])
+def test_step_golden(path):
+    import ccfindr_amd as C
+    z = np.load(path)
+    got = C.nmf_update(z["X"], z["w0"], z["h0"], prior=bool(z["prior"]), gamma_a=float(z["gamma"][0]), gamma_b=float(z["gamma"][1]))
+    check(got, z["ew"], z["eh"], float(z["lk"]))
+
+
+def test_trajectory_and_stop_golden():
+    import ccfindr_amd as C
+    z = np.load(os.path.join(GOLD, "ml_traj_120x200_r3.npz"))
+    eng = C.VBEngine(C.CountMatrix(z["X"]), 3)
+    eng.ml_set_state(z["w0"], z["h0"])
+    lk = [eng.ml_step() for _ in range(60)]
+    st = eng.ml_get_state()
+    assert max(abs(a / b - 1) for a, b in zip(lk, z["lk"])) <= 1e-9
+    assert relerr(st["ew"], z["ew60"]) <= 1e-9 and relerr(st["eh"], z["eh60"]) <= 1e-9
+    # the loop's stopping rule (R/factorize.R:211): same iteration as the oracle's run
+    eng.ml_set_state(z["w0"], z["h0"])
+    lkold, it = -np.inf, 0
+    for it in range(1, 2001):
+        lk0 = eng.ml_step()
+        if abs(lkold - lk0) < float(z["tol"]) * abs(lkold):
+            break
+        lkold = lk0
+    eng.close()
+    assert it == int(z["it"]) and abs(lk0 / float(z["lk_stop"]) - 1) <= 1e-9
+
+
+def test_pbmc_sample_golden_sparse_input():
+    """The reference's bundled PBMC sample as dgCMatrix slots, never densified."""
+    import ccfindr_amd as C
+    z = np.load(os.path.join(GOLD, "ml_pbmc_extdata_r5.npz"))
+    d = np.load(os.path.join(GOLD, "pbmc_extdata_r5.npz"))
+    n, m = int(d["n"]), int(d["m"])
+    X = sp.csc_matrix((d["data"].astype(np.float64), d["indices"], d["indptr"]), shape=(n, m))
+    eng = C.VBEngine(C.CountMatrix(X), 5)
+    eng.ml_set_state(z["w0"], z["h0"])
+    lk = [eng.ml_step() for _ in range(20)]
+    st = eng.ml_get_state()
+    eng.close()
+    assert max(abs(a / b - 1) for a, b in zip(lk, z["lk"])) <= 1e-10
+    assert relerr(st["ew"], z["ew20"]) <= 1e-10 and relerr(st["eh"], z["eh20"]) <= 1e-10
+
+
+def test_c3_full_size_against_stored_entries_oracle_and_monotone():
+    """BASELINE.json's C3 (20 000 x 50 000, ~5 % stored, rank 10): two steps against the OpenMP oracle, then the
+    size-independent property of the multiplicative updates -- the likelihood never decreases."""
+    import os as _os
+    import ccfindr_amd as C
+    from ccfindr_amd import synth
+    from oracle import mlnmf_oracle as O
+    n, m, r, k = 20000, 50000, 10, 10
+    depth = np.round(np.random.default_rng(3).lognormal(np.log(1500.0), 0.3, size=m)).astype(np.int64)
+    X = synth.fill_empty(synth.simulate_data(n, [m // k] * k, alpha0=0.065, seed=3, depth=depth), seed=3)
+    w, h = uniform_state(n, m, r, seed=71)
+    eng = C.VBEngine(C.CountMatrix(X), r)
+    eng.ml_set_state(w, h)
+    S = X.tocsc()
+    nt = min(16, len(_os.sched_getaffinity(0)))
+    for _ in range(2):
+        lk = eng.ml_step()
+        o = O.update_csc(n, m, S.indptr, S.indices, S.data, w, h, nthreads=nt)
+        w, h = o["ew"], o["eh"]
+        assert abs(lk / o["lk"] - 1) <= 1e-10, (lk, o["lk"])
+    st = eng.ml_get_state()
+    assert relerr(st["ew"], w) <= 1e-10 and relerr(st["eh"], h) <= 1e-10
+    prev = lk
+    for _ in range(30):
+        lk = eng.ml_step()
+        assert lk >= prev - 1e-13 * abs(prev)
+        prev = lk
+    eng.close()
