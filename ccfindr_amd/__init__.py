@@ -10,6 +10,8 @@ from .engine import EPS, CountMatrix, VBEngine  # noqa: F401
 from .bayesian import (VBResult, hyper_update, vb_factorize, vb_init, vb_iterate,  # noqa: F401
                        vbnmf_update)
 
+from .io import CountData, read_10x, remove_zeros, write_10x  # noqa: F401
+from .post import cluster_id  # noqa: F401
 from .factorize import MLResult, factorize, likelihood, nmf_update  # noqa: F401
 
 __version__ = "0.1.0"

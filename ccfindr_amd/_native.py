@@ -57,6 +57,9 @@ SIGNATURES = {
     "vbnmf_matrix_from_dense": (ctypes.c_int, [_I64, _I64, c_double_p, _VPP]),
     "vbnmf_matrix_from_csc": (ctypes.c_int, [_I64, _I64, c_int32_p, c_int32_p, c_double_p, _VPP]),
     "vbnmf_matrix_from_csr": (ctypes.c_int, [_I64, _I64, c_int32_p, c_int32_p, c_double_p, _VPP]),
+    "vbnmf_matrix_from_mtx": (ctypes.c_int, [ctypes.c_char_p, _VPP]),
+    "vbnmf_matrix_write_mtx": (ctypes.c_int, [_VP, ctypes.c_char_p]),
+    "vbnmf_matrix_csc": (ctypes.c_int, [_VP, ctypes.POINTER(c_int64_p), ctypes.POINTER(c_int32_p), ctypes.POINTER(c_double_p)]),
     "vbnmf_matrix_info": (ctypes.c_int, [_VP, c_int64_p, c_int64_p, c_int64_p, c_double_p]),
     "vbnmf_matrix_empty_counts": (ctypes.c_int, [_VP, c_int64_p, c_int64_p]),
     "vbnmf_matrix_destroy": (None, [_VP]),

@@ -175,7 +175,34 @@ def vb_init(nrow, ncol, mat, rank, hyper, initializer, max=1.0, rng=None):
         h = h * scale
         w = w / scale
     elif initializer == "svd":
-        raise NotImplementedError("initializer 'svd' (reference R/bayesian.R:116-149) is not built; use 'svd2' or 'random'")
+        # NNDSVD-like start, reference R/bayesian.R:116-149, kept literally -- including :132-133, where the
+        # norms of the NEGATIVE parts are computed from the positive parts (xp, yp), so mn == mp and the
+        # positive branch (:135-138) is always taken; and :125, whose seq(2, rank) makes rank = 1 an error in R.
+        if rank < 2:
+            raise ValueError("initializer 'svd' needs rank >= 2 (reference R/bayesian.R:125 indexes component 2)")
+        A = mat.toarray() if hasattr(mat, "toarray") else np.asarray(mat, dtype=np.float64)
+        u, d, vt = np.linalg.svd(A, full_matrices=False)                                        # :119
+        w = np.zeros((nrow, rank)); h = np.zeros((rank, ncol))                                  # :117-118
+        d1 = np.sqrt(d[0])                                                                      # :120
+        w[:, 0] = d1 * u[:, 0]                                                                  # :121
+        sgn = np.sign(w[0, 0])                                                                  # :122
+        if sgn < 0:
+            w = -w                                                                              # :123
+        h[0, :] = sgn * d1 * vt[0, :]                                                           # :124
+        for k in range(1, rank):                                                                # :125
+            x, y = u[:, k], vt[k, :]
+            xp, yp = np.where(x > 0, x, 0.0), np.where(y > 0, y, 0.0)                           # :128-129
+            xn, yn = np.where(x < 0, -x, 0.0), np.where(y < 0, -y, 0.0)                         # :130-131
+            xpnrm, ypnrm = np.sqrt(np.sum(xp ** 2)), np.sqrt(np.sum(yp ** 2))                   # :132-133
+            mp = xpnrm * ypnrm
+            xnnrm, ynnrm = np.sqrt(np.sum(xp ** 2)), np.sqrt(np.sum(yp ** 2))                   # :135-136 (sic: xp, yp)
+            mn = xnnrm * ynnrm
+            if mp >= mn:                                                                        # :138
+                uu, vv, sig = xp / xpnrm, yp / ypnrm, mp
+            else:
+                uu, vv, sig = xn / xnnrm, yn / ynnrm, mn
+            w[:, k] = np.sqrt(d[k] * sig) * uu                                                  # :147
+            h[k, :] = np.sqrt(d[k] * sig) * vv                                                  # :148
     else:
         raise ValueError("Unknown initializer")                                                 # :160
     dw = np.zeros((nrow, rank)); dh = np.zeros((rank, ncol))

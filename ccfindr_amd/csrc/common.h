@@ -101,6 +101,9 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
 
 const char *last_error_cstr();
 
+// Canonical matrix from compressed columns in any order within a column (duplicates summed, zeros dropped).
+int matrix_from_csc(int64_t n, int64_t m, const int32_t *p, const int32_t *i, const double *x, Matrix &X);
+
 }  // namespace vbnmf
 
 // opaque handles of the C ABI
@@ -111,3 +114,8 @@ struct vbnmf_matrix {
 struct vbnmf_layout {
     vbnmf::Layout L;
 };
+
+namespace vbnmf {
+// Allocates the handle, runs `fill` on its matrix and finishes it (sum lgamma(x+1)); maps exceptions to codes.
+int new_matrix(vbnmf_matrix **out, const std::function<int(Matrix &)> &fill);
+}

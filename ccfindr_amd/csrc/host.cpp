@@ -167,7 +167,7 @@ static int canonicalise(int64_t nouter, int64_t ninner, const int32_t *p, const 
     return VBNMF_OK;
 }
 
-static int matrix_from_csc(int64_t n, int64_t m, const int32_t *p, const int32_t *i, const double *x, Matrix &X)
+int matrix_from_csc(int64_t n, int64_t m, const int32_t *p, const int32_t *i, const double *x, Matrix &X)
 {
     X.n = n; X.m = m;
     int rc = canonicalise(m, n, p, i, x, X.colptr, X.row, X.val);
@@ -653,7 +653,9 @@ extern "C" {
 const char *vbnmf_last_error(void) { return vbnmf::last_error_cstr(); }
 const char *vbnmf_version(void) { return "0.1.0"; }
 
-static int new_matrix(vbnmf_matrix **out, const std::function<int(Matrix &)> &fill)
+}  // extern "C"
+
+int vbnmf::new_matrix(vbnmf_matrix **out, const std::function<int(Matrix &)> &fill)
 {
     if (!out) return fail(VBNMF_ERR_BAD_ARG, "out pointer is NULL");
     *out = nullptr;
@@ -673,6 +675,8 @@ static int new_matrix(vbnmf_matrix **out, const std::function<int(Matrix &)> &fi
     *out = X;
     return VBNMF_OK;
 }
+
+extern "C" {
 
 static int check_dims(int64_t n, int64_t m)
 {

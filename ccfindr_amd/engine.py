@@ -8,6 +8,7 @@ R/bayesian.R:239): the genes x cells count matrix, dense or ``dgCMatrix``-like s
 from __future__ import annotations
 
 import ctypes
+import os
 
 import numpy as np
 
@@ -72,6 +73,38 @@ class CountMatrix:
         self.nnz = nnz_.value
         self.sum_lgamma_x1 = lgx.value
         return self
+
+    @classmethod
+    def from_mtx(cls, path):
+        """A Matrix Market file, parsed natively into compressed columns (reference R/utils.R:34:
+        ``as(Matrix::readMM(count), 'dgCMatrix')``)."""
+        self = cls.__new__(cls)
+        L = N.load()
+        self._lib = L
+        self._h = ctypes.c_void_p()
+        N.check(L.vbnmf_matrix_from_mtx(os.fsencode(path), ctypes.byref(self._h)))
+        n_, m_, nnz_ = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        lgx = ctypes.c_double()
+        N.check(L.vbnmf_matrix_info(self._h, ctypes.byref(n_), ctypes.byref(m_), ctypes.byref(nnz_), ctypes.byref(lgx)))
+        self.shape = (n_.value, m_.value)
+        self.nnz = nnz_.value
+        self.sum_lgamma_x1 = lgx.value
+        return self
+
+    def write_mtx(self, path):
+        """``Matrix::writeMM`` of the counts (reference R/utils.R:876)."""
+        N.check(self._lib.vbnmf_matrix_write_mtx(self._h, os.fsencode(path)))
+
+    def to_scipy(self):
+        """The canonical compressed columns as a scipy ``csc_matrix`` (a copy)."""
+        import scipy.sparse as sp
+        cp, ri, xv = N.c_int64_p(), N.c_int32_p(), N.c_double_p()
+        N.check(self._lib.vbnmf_matrix_csc(self._h, ctypes.byref(cp), ctypes.byref(ri), ctypes.byref(xv)))
+        n, m = self.shape
+        indptr = np.ctypeslib.as_array(cp, shape=(m + 1,)).copy()
+        indices = np.ctypeslib.as_array(ri, shape=(max(self.nnz, 1),))[:self.nnz].copy()
+        data = np.ctypeslib.as_array(xv, shape=(max(self.nnz, 1),))[:self.nnz].copy()
+        return sp.csc_matrix((data, indices, indptr), shape=(n, m))
 
     def empty_counts(self):
         """(# all-zero rows, # all-zero columns): the guards of reference R/bayesian.R:244-247."""

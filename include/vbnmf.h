@@ -72,6 +72,19 @@ int vbnmf_matrix_from_csc(int64_t n, int64_t m, const int32_t *p, const int32_t 
 /* Compressed sparse rows: p = n+1 row pointers, j = 0-based column indices. */
 int vbnmf_matrix_from_csr(int64_t n, int64_t m, const int32_t *p, const int32_t *j,
                           const double *x, vbnmf_matrix **out);
+/* Matrix Market file: what read_10x hands the reference through
+ * as(Matrix::readMM(count), 'dgCMatrix') (R/utils.R:34; e.g. inst/extdata/matrix.mtx:1-2).
+ * Coordinate real / integer / pattern, general / symmetric / skew-symmetric, or the dense
+ * array form; 1-based indices; repeated (i, j) are summed; explicit zeros are dropped.
+ * Parsed by all host threads straight into compressed columns. */
+int vbnmf_matrix_from_mtx(const char *path, vbnmf_matrix **out);
+/* The file Matrix::writeMM writes in write_10x (R/utils.R:876): coordinate, general,
+ * "integer" when every stored value is one (else "real"), entries by columns. */
+int vbnmf_matrix_write_mtx(const vbnmf_matrix *X, const char *path);
+/* Read-only view of the canonical compressed columns (m+1 pointers, rows ascending in each
+ * column, no zeros); the arrays belong to the handle. */
+int vbnmf_matrix_csc(const vbnmf_matrix *X, const int64_t **colptr, const int32_t **row,
+                     const double **val);
 /* n, m, stored entries, sum lgamma(x+1); any out pointer may be NULL. */
 int vbnmf_matrix_info(const vbnmf_matrix *X, int64_t *n, int64_t *m, int64_t *nnz,
                       double *sum_lgamma_x1);

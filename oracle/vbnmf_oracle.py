@@ -237,3 +237,36 @@ def vb_iterate(update, wh, hyper, Itmax=10000, Tol=1e-5, hyper_flags=(True,) * 4
             break
         lk0 = wh["lkh"]                                                     # :348
     return wh, hyper, lk0, it, trace
+
+
+def vb_init_svd(mat, rank):
+    """vb_init(..., initializer='svd'), R/bayesian.R:116-149, element by element as the R code walks it
+    (vapply per entry), quirks included (:135-136 take the norms of xp, yp again)."""
+    A = np.asarray(mat.toarray() if hasattr(mat, "toarray") else mat, dtype=np.float64)
+    nrow, ncol = A.shape
+    U, D, Vt = np.linalg.svd(A, full_matrices=False)
+    w = np.zeros((nrow, rank)); h = np.zeros((rank, ncol))
+    d1 = D[0] ** 0.5
+    for i in range(nrow):
+        w[i, 0] = d1 * U[i, 0]
+    sgn = int(w[0, 0] > 0) - int(w[0, 0] < 0)
+    if sgn < 0:
+        w = -w
+    for j in range(ncol):
+        h[0, j] = sgn * d1 * Vt[0, j]
+    for k in range(1, rank):
+        x, y = U[:, k], Vt[k, :]
+        xp = np.array([v if v > 0 else 0.0 for v in x]); yp = np.array([v if v > 0 else 0.0 for v in y])
+        xn = np.array([-v if v < 0 else 0.0 for v in x]); yn = np.array([-v if v < 0 else 0.0 for v in y])
+        xpnrm = sum(v * v for v in xp) ** 0.5; ypnrm = sum(v * v for v in yp) ** 0.5
+        mp = xpnrm * ypnrm
+        xnnrm = sum(v * v for v in xp) ** 0.5; ynnrm = sum(v * v for v in yp) ** 0.5
+        mn = xnnrm * ynnrm
+        if mp >= mn:
+            u, v, sig = xp / xpnrm, yp / ypnrm, mp
+        else:
+            u, v, sig = xn / xnnrm, yn / ynnrm, mn
+        w[:, k] = (D[k] * sig) ** 0.5 * u
+        h[k, :] = (D[k] * sig) ** 0.5 * v
+    return {"w": w, "h": h, "lw": w.copy(), "lh": h.copy(), "ew": w.copy(), "eh": h.copy(),
+            "dw": np.zeros((nrow, rank)), "dh": np.zeros((rank, ncol))}

@@ -172,3 +172,32 @@ def test_lpt_schedule_and_partition():
     parts = parallel.cell_partition(50001, 8)
     assert parts[0][0] == 0 and parts[-1][1] == 50001 and all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
     assert max(e - b for b, e in parts) - min(e - b for b, e in parts) <= 1
+
+
+def test_vb_init_svd_matches_oracle_restatement_and_is_nonnegative():
+    """initializer = 'svd' (reference R/bayesian.R:116-149), quirks kept."""
+    from ccfindr_amd import bayesian
+    from oracle import vbnmf_oracle as O
+    rng = np.random.default_rng(12)
+    X = rng.poisson(1.2, size=(40, 55)).astype(np.float64)
+    hy = {"aw": 1.0, "bw": 1.0, "ah": 1.0, "bh": 1.0}
+    for rank in (2, 5):
+        got = bayesian.vb_init(40, 55, X, rank, hy, "svd")
+        want = O.vb_init_svd(X, rank)
+        for k in ("w", "h", "lw", "lh", "ew", "eh", "dw", "dh"):
+            assert np.allclose(got[k], want[k], rtol=1e-13, atol=0), k
+        assert (got["w"] >= 0).all() and (got["h"] >= 0).all()
+        # the leading pair is the Perron pair of a non-negative matrix: strictly positive, and alone it is the best rank-1 fit
+        u, d, vt = np.linalg.svd(X, full_matrices=False)
+        assert np.allclose(np.outer(got["w"][:, 0], got["h"][0]), d[0] * np.outer(u[:, 0], vt[0]), rtol=1e-12, atol=1e-12)
+    with pytest.raises(ValueError, match="rank >= 2"):
+        bayesian.vb_init(40, 55, X, 1, hy, "svd")
+
+
+def test_cluster_id_is_one_based_first_maximum():
+    import ccfindr_amd as C
+    res = C.VBResult(ranks=[2, 3], coeff=[np.array([[1.0, 0.2], [0.5, 0.9]]), np.array([[0.1, 3.0, 2.0], [0.7, 3.0, 2.0], [0.7, 1.0, 5.0]])])
+    assert C.cluster_id(res, 2).tolist() == [1, 2]
+    assert C.cluster_id(res, 3).tolist() == [2, 1, 3]
+    with pytest.raises(IndexError):
+        C.cluster_id(res, 4)
