@@ -38,10 +38,9 @@ class LayoutView(ctypes.Structure):
         ("side", ctypes.c_int32), ("wide", ctypes.c_int32),
         ("n_major", ctypes.c_int64), ("n_minor", ctypes.c_int64),
         ("block_width", ctypes.c_int32), ("n_blocks", ctypes.c_int32), ("max_len", ctypes.c_int32), ("n_wg", ctypes.c_int32),
-        ("n_waves", ctypes.c_int32),
         ("n_tasks", ctypes.c_int64), ("n_slices", ctypes.c_int64), ("n_slots", ctypes.c_int64), ("n_segs", ctypes.c_int64),
         ("task_major", c_uint32_p), ("slice_width", c_int32_p), ("slice_off", c_int64_p), ("slice_block", c_int32_p),
-        ("seg_block", c_int32_p), ("wg_seg0", c_int32_p), ("segwave_ptr", c_int32_p), ("segwave_slice", c_int32_p),
+        ("seg_block", c_int32_p), ("wg_seg0", c_int32_p), ("seg_ptr", c_int32_p),
         ("inv_ptr", c_int32_p), ("inv_task", c_uint32_p),
         ("packed", c_uint32_p), ("wide_idx", c_uint32_p), ("wide_val", c_double_p),
     ]

@@ -45,8 +45,9 @@ double sum_xlogx(const Matrix &X, int64_t cb, int64_t ce);
 // the resulting work list holds a mix of long and short slices; the list is cut into `n_wg`
 // stretches of equal cost, one per persistent workgroup; a *segment* is the part of a
 // stretch that lies in one block (the workgroup stages that block of the gathered factor in
-// LDS once per segment), and inside a segment the slices are bin-packed onto the workgroup's
-// `n_waves` waves (longest first, to the least loaded wave).
+// LDS once per segment).  Slices are numbered in processing order -- workgroup by workgroup,
+// segment by segment, longest first inside a segment -- and the waves of the workgroup pull
+// them through a ticket counter, so a segment is just the id range [seg_ptr[g], seg_ptr[g+1]).
 constexpr int kLanes = 64;          // one slice = one wavefront
 constexpr int kUnroll = 4;          // entries per lane per 16-byte load
 constexpr int kWidthQuantum = 8;    // slice widths are multiples of this (two loads per loop trip)
@@ -56,7 +57,7 @@ struct Layout {
     int side = 0;                   // 0: lanes own genes, minors = cells; 1: lanes own cells, minors = genes
     bool wide = false;
     int64_t n_major = 0, n_minor = 0;
-    int32_t block_width = 0, n_blocks = 0, max_len = 0, n_wg = 0, n_waves = 0;
+    int32_t block_width = 0, n_blocks = 0, max_len = 0, n_wg = 0;
     int64_t n_tasks = 0, n_slices = 0, n_slots = 0, n_segs = 0, nnz = 0;
     std::vector<uint32_t> task_major;    // n_slices * 64 ; kIdleLane pads a block's last slice
     std::vector<int32_t> slice_width;    // n_slices ; entries per lane, multiple of 4
@@ -64,8 +65,7 @@ struct Layout {
     std::vector<int32_t> slice_block;    // n_slices ; minor block (host-side bookkeeping / tests)
     std::vector<int32_t> seg_block;      // n_segs
     std::vector<int32_t> wg_seg0;        // n_wg + 1
-    std::vector<int32_t> segwave_ptr;    // n_segs * n_waves + 1 : slices of (segment, wave) ...
-    std::vector<int32_t> segwave_slice;  // n_slices             : ... in processing order
+    std::vector<int32_t> seg_ptr;        // n_segs + 1 : first slice of each segment
     std::vector<int32_t> inv_ptr;        // n_major + 1 : tasks of each major ...
     std::vector<uint32_t> inv_task;      // n_tasks     : ... as slice*64+lane ids, in (block, position) order
     std::vector<uint32_t> packed;        // n_slots (wide == false)
@@ -77,7 +77,6 @@ struct LayoutParams {
     int32_t block_width;   // minors per LDS block
     int32_t max_len;       // longest task (entries), multiple of 4
     int32_t n_wg;          // persistent workgroups of the sweep kernel
-    int32_t n_waves;       // waves per workgroup
 };
 
 // Padded rank used on the device (even, so a factor row is a whole number of 16-byte LDS reads).

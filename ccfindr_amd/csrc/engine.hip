@@ -34,7 +34,7 @@ namespace {
 struct DeviceSide {
     uint32_t *packed = nullptr, *widx = nullptr, *task_major = nullptr, *inv_task = nullptr;
     double *wval = nullptr;
-    int32_t *slice_width = nullptr, *seg_block = nullptr, *segwave_ptr = nullptr, *segwave_slice = nullptr, *wg_seg0 = nullptr, *inv_ptr = nullptr;
+    int32_t *slice_width = nullptr, *seg_block = nullptr, *seg_ptr = nullptr, *wg_seg0 = nullptr, *inv_ptr = nullptr;
     int64_t *slice_off = nullptr;
     double *part = nullptr;
     int64_t n_major = 0, n_minor = 0, n_tasks = 0, n_slices = 0, n_slots = 0;
@@ -103,7 +103,7 @@ namespace {
 void free_side(DeviceSide &S)
 {
     (void)hipFree(S.packed); (void)hipFree(S.widx); (void)hipFree(S.wval); (void)hipFree(S.task_major);
-    (void)hipFree(S.inv_task); (void)hipFree(S.slice_width); (void)hipFree(S.seg_block); (void)hipFree(S.segwave_ptr); (void)hipFree(S.segwave_slice);
+    (void)hipFree(S.inv_task); (void)hipFree(S.slice_width); (void)hipFree(S.seg_block); (void)hipFree(S.seg_ptr);
     (void)hipFree(S.wg_seg0); (void)hipFree(S.inv_ptr); (void)hipFree(S.slice_off); (void)hipFree(S.part);
     S = DeviceSide();
 }
@@ -122,8 +122,7 @@ int upload_side(const Layout &L, int R, DeviceSide &S)
     if (int rc = dev_upload(&S.slice_width, L.slice_width)) return rc;
     if (int rc = dev_upload(&S.slice_off, L.slice_off)) return rc;
     if (int rc = dev_upload(&S.seg_block, L.seg_block)) return rc;
-    if (int rc = dev_upload(&S.segwave_ptr, L.segwave_ptr)) return rc;
-    if (int rc = dev_upload(&S.segwave_slice, L.segwave_slice)) return rc;
+    if (int rc = dev_upload(&S.seg_ptr, L.seg_ptr)) return rc;
     if (int rc = dev_upload(&S.wg_seg0, L.wg_seg0)) return rc;
     if (int rc = dev_upload(&S.inv_ptr, L.inv_ptr)) return rc;
     if (int rc = dev_upload(&S.inv_task, L.inv_task)) return rc;
@@ -136,7 +135,7 @@ SweepSide sweep_side_args(const vbnmf_engine *e, const DeviceSide &S, bool gene_
     SweepSide P;
     P.packed = S.packed; P.widx = S.widx; P.wval = S.wval;
     P.task_major = S.task_major; P.slice_width = S.slice_width; P.slice_off = S.slice_off;
-    P.seg_block = S.seg_block; P.wg_seg0 = S.wg_seg0; P.segwave_ptr = S.segwave_ptr; P.segwave_slice = S.segwave_slice;
+    P.seg_block = S.seg_block; P.wg_seg0 = S.wg_seg0; P.seg_ptr = S.seg_ptr;
     P.F = gene_side ? e->lw : e->lh;
     P.llF = gene_side ? e->llw : e->llh;
     P.G = gene_side ? e->lh : e->lw;

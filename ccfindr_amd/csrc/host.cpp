@@ -293,14 +293,13 @@ LayoutParams default_layout_params(int64_t n_major, int64_t n_minor, int R, int 
     if (n_wg <= 0) n_wg = env_int("VBNMF_NWG", 256);
     if (n_wg < 1) n_wg = 1;
     lp.n_wg = n_wg;
-    lp.n_waves = sweep_threads(R) / kLanes;
     return lp;
 }
 
 int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const LayoutParams &lp, Layout &L)
 {
     if (cb < 0 || ce > X.m || cb >= ce) return fail(VBNMF_ERR_BAD_ARG, "column range [%lld, %lld) is outside the matrix", (long long)cb, (long long)ce);
-    if (lp.block_width <= 0 || lp.block_width > 65536 || lp.max_len <= 0 || lp.max_len % kWidthQuantum || lp.n_wg <= 0 || lp.n_waves <= 0)
+    if (lp.block_width <= 0 || lp.block_width > 65536 || lp.max_len <= 0 || lp.max_len % kWidthQuantum || lp.n_wg <= 0)
         return fail(VBNMF_ERR_BAD_ARG, "bad layout parameters");
 
     // major-compressed view of X[:, cb:ce)
@@ -323,7 +322,6 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
     L.block_width = lp.block_width;
     L.max_len = lp.max_len;
     L.n_wg = lp.n_wg;
-    L.n_waves = lp.n_waves;
     const int64_t nmaj = L.n_major;
     const int32_t C = L.block_width;
     const int32_t nblk = (int32_t)((L.n_minor + C - 1) / C);
@@ -497,33 +495,30 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
         }
         L.wg_seg0.assign(L.n_wg + 1, 0);
         L.seg_block.clear();
-        L.segwave_ptr.assign(1, 0);
-        L.segwave_slice.clear();
-        L.segwave_slice.reserve(L.n_slices);
+        L.seg_ptr.assign(1, 0);
+        std::vector<int32_t> order;                           // order[new slice id] = id before the renumbering below
+        order.reserve(L.n_slices);
         // Inside a share the waves take slices DYNAMICALLY (an LDS ticket counter), longest first: the
         // hardware issues the oldest wave of a SIMD first, so equal static shares finish far apart
         // (measured: 50 / 75 / 99 us for the three waves of a SIMD) while greedy longest-first pulling
         // ends all waves within one slice of each other.  Which wave runs a slice does not change any
         // result (per-task partials; per-slice evidence partials summed in list order).
-        L.n_waves = 1;
         for (int w = 0; w < L.n_wg; w++) {
             L.wg_seg0[w] = (int32_t)L.seg_block.size();
             for (auto &seg : shares[w]) {
                 std::vector<int32_t> &sl = seg.second;
                 std::stable_sort(sl.begin(), sl.end(), [&](int32_t x, int32_t y) { return L.slice_width[x] > L.slice_width[y]; });
                 L.seg_block.push_back(seg.first);
-                L.segwave_slice.insert(L.segwave_slice.end(), sl.begin(), sl.end());
-                L.segwave_ptr.push_back((int32_t)L.segwave_slice.size());
+                order.insert(order.end(), sl.begin(), sl.end());
+                L.seg_ptr.push_back((int32_t)order.size());
             }
         }
         L.wg_seg0[L.n_wg] = (int32_t)L.seg_block.size();
         L.n_segs = (int64_t)L.seg_block.size();
-    }
 
-    // Renumber the slices in processing order, so that list position == slice id: the kernel then finds
-    // a slice's width, offset, majors and partial rows directly from its ticket, with no indirection.
-    {
-        const std::vector<int32_t> ord(L.segwave_slice);     // ord[new id] = old id
+        // Renumber the slices in processing order, so that list position == slice id: the kernel then finds
+        // a slice's width, offset, majors and partial rows directly from its ticket, with no indirection.
+        const std::vector<int32_t> &ord = order;
         std::vector<int32_t> w2(L.n_slices), b2(L.n_slices), len2((size_t)L.n_slices * kLanes);
         std::vector<uint32_t> maj2((size_t)L.n_slices * kLanes);
         std::vector<int64_t> pos2((size_t)L.n_slices * kLanes);
@@ -535,7 +530,6 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
                 pos2[(size_t)s * kLanes + l] = task_pos[(size_t)o * kLanes + l];
                 len2[(size_t)s * kLanes + l] = task_len[(size_t)o * kLanes + l];
             }
-            L.segwave_slice[s] = (int32_t)s;
         }
         L.slice_width.swap(w2); L.slice_block.swap(b2); L.task_major.swap(maj2); task_pos.swap(pos2); task_len.swap(len2);
         int64_t o2 = 0;
@@ -761,12 +755,11 @@ int vbnmf_layout_build(const vbnmf_matrix *X, int64_t col_begin, int64_t col_end
     view->side = L.side; view->wide = L.wide ? 1 : 0;
     view->n_major = L.n_major; view->n_minor = L.n_minor;
     view->block_width = L.block_width; view->n_blocks = L.n_blocks; view->max_len = L.max_len; view->n_wg = L.n_wg;
-    view->n_waves = L.n_waves;
     view->n_tasks = L.n_tasks; view->n_slices = L.n_slices; view->n_slots = L.n_slots; view->n_segs = L.n_segs;
     view->task_major = L.task_major.data(); view->slice_width = L.slice_width.data();
     view->slice_off = L.slice_off.data(); view->slice_block = L.slice_block.data();
     view->seg_block = L.seg_block.data(); view->wg_seg0 = L.wg_seg0.data();
-    view->segwave_ptr = L.segwave_ptr.data(); view->segwave_slice = L.segwave_slice.data();
+    view->seg_ptr = L.seg_ptr.data();
     view->inv_ptr = L.inv_ptr.data(); view->inv_task = L.inv_task.data();
     view->packed = L.wide ? nullptr : L.packed.data();
     view->wide_idx = L.wide ? L.wide_idx.data() : nullptr;

@@ -43,8 +43,7 @@ struct SweepSide {
     const int64_t *slice_off;      // [n_slices]
     const int32_t *seg_block;      // [n_segs]
     const int32_t *wg_seg0;        // [n_wg + 1]
-    const int32_t *segwave_ptr;    // [n_segs * waves + 1]
-    const int32_t *segwave_slice;  // [n_slices] slices of (segment, wave) in processing order
+    const int32_t *seg_ptr;        // [n_segs + 1] first slice of each segment (slices are numbered in processing order)
     const double *F;               // [n_major][R]  factor owned by the lanes
     const double *llF;             // [n_major][R]  F * log F
     const double *G;               // [n_minor][R]  factor gathered through LDS
@@ -189,7 +188,7 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
         // The waves pull slices from the segment's list (longest first) through an LDS ticket counter, in
         // chunks of kLdsEvSlots so every slice's evidence partial has an LDS slot; after a chunk the slots
         // are added in list order, so the sum does not depend on which wave ran which slice.
-        const int l0 = S.segwave_ptr[seg], l1 = S.segwave_ptr[seg + 1];
+        const int l0 = S.seg_ptr[seg], l1 = S.seg_ptr[seg + 1];
         for (int c0 = l0; c0 < l1; c0 += kLdsEvSlots) {
         const int cn = min(kLdsEvSlots, l1 - c0);
         while (true) {

@@ -249,7 +249,6 @@ typedef struct {
     int32_t n_blocks;              /* ceil(n_minor / block_width) */
     int32_t max_len;               /* longest task (entries per lane) */
     int32_t n_wg;                  /* persistent workgroups the work list is cut for */
-    int32_t n_waves;               /* waves per workgroup the slices of a segment are packed onto */
     int64_t n_tasks, n_slices;     /* task = run of one major's entries in one block; slice = 64 tasks */
     int64_t n_slots;               /* padded entry slots (all slices) */
     int64_t n_segs;                /* segment = the slices of one block in one workgroup's share */
@@ -260,8 +259,7 @@ typedef struct {
     const int32_t *slice_block;    /* [n_slices] minor block */
     const int32_t *seg_block;      /* [n_segs] */
     const int32_t *wg_seg0;        /* [n_wg+1] segments of each workgroup */
-    const int32_t *segwave_ptr;    /* [n_segs*n_waves+1] slices of (segment, wave) ... */
-    const int32_t *segwave_slice;  /* [n_slices]         ... in processing order */
+    const int32_t *seg_ptr;        /* [n_segs+1] first slice of each segment; slices are numbered in processing order */
     const int32_t *inv_ptr;        /* [n_major+1] tasks of each major ... */
     const uint32_t *inv_task;      /* [n_tasks]   ... in the order their partials are summed */
     const uint32_t *packed;        /* [n_slots] (count << 16) | local minor    (wide == 0) */

@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 import scipy.sparse as sp
 
-from util_layout import build_layout, reconstruct
+from util_layout import build_layout, reconstruct, workgroup_balance
 
 
 def _counts(n, m, lam, seed):
@@ -68,6 +68,18 @@ def test_padding_is_small_on_skewed_data():
     for side in (0, 1):
         v = build_layout(M, side, 10)
         assert v["n_slots"] <= 1.12 * M.nnz, (side, v["n_slots"] / M.nnz)
+
+
+def test_workgroup_shares_are_balanced(monkeypatch):
+    """Whole workgroups per block by cost, a block's slices snake-dealt: no share far above the mean."""
+    import ccfindr_amd as C
+    monkeypatch.setenv("VBNMF_NWG", "16")          # ~11 slices per workgroup on this small matrix
+    from ccfindr_amd import synth
+    X = synth.fill_empty(synth.simulate_data(3000, [2000] * 3, alpha0=0.065, seed=5, depth=np.full(6000, 300)))
+    M = C.CountMatrix(X)
+    for side in (0, 1):
+        cost = workgroup_balance(build_layout(M, side, 10))
+        assert cost.min() > 0 and cost.max() <= 1.25 * cost.mean(), (side, cost.max() / cost.mean())
 
 
 def test_ingestion_canonicalises_unsorted_duplicates_and_zeros():

@@ -15,15 +15,14 @@ def build_layout(M, side, r, cols=None):
     N.check(L.vbnmf_layout_build(M._h, cb, ce, side, r, ctypes.byref(h), ctypes.byref(v)))
     try:
         out = {k: getattr(v, k) for k in ("side", "wide", "n_major", "n_minor", "block_width", "n_blocks", "max_len",
-                                          "n_wg", "n_waves", "n_tasks", "n_slices", "n_slots", "n_segs")}
+                                          "n_wg", "n_tasks", "n_slices", "n_slots", "n_segs")}
         arr = lambda p, cnt: np.ctypeslib.as_array(p, shape=(cnt,)).copy() if cnt else np.zeros(0, dtype=np.int64)
         out["task_major"] = arr(v.task_major, v.n_slices * 64)
         out["slice_width"] = arr(v.slice_width, v.n_slices)
         out["slice_off"] = arr(v.slice_off, v.n_slices)
         out["slice_block"] = arr(v.slice_block, v.n_slices)
         out["seg_block"] = arr(v.seg_block, v.n_segs)
-        out["segwave_ptr"] = arr(v.segwave_ptr, v.n_segs * v.n_waves + 1)
-        out["segwave_slice"] = arr(v.segwave_slice, v.n_slices)
+        out["seg_ptr"] = arr(v.seg_ptr, v.n_segs + 1)
         out["wg_seg0"] = arr(v.wg_seg0, v.n_wg + 1)
         out["inv_ptr"] = arr(v.inv_ptr, v.n_major + 1)
         out["inv_task"] = arr(v.inv_task, v.n_tasks)
@@ -86,29 +85,20 @@ def reconstruct(view):
         fm = [first_minor[int(t)] for t in ids]
         assert fm == sorted(fm)
     assert (seen[view["task_major"] != 0xFFFFFFFF] == 1).all() and seen.sum() == view["n_tasks"]
-    # persistent workgroups: every slice is handed to exactly one (segment, wave); one block per segment
+    # persistent workgroups: the segments tile the slice ids in order; one block per segment; inside a segment
+    # the slices (pulled through the ticket counter in id order) go longest first
     assert view["wg_seg0"][0] == 0 and view["wg_seg0"][-1] == view["n_segs"]
     assert np.all(np.diff(view["wg_seg0"]) >= 0)
-    NW = view["n_waves"]
-    ptr = view["segwave_ptr"]
-    assert ptr[0] == 0 and ptr[-1] == view["n_slices"] and np.all(np.diff(ptr) >= 0)
-    assert sorted(view["segwave_slice"].tolist()) == list(range(view["n_slices"]))
+    ptr = view["seg_ptr"]
+    assert ptr[0] == 0 and ptr[-1] == view["n_slices"] and np.all(np.diff(ptr) > 0)
     for g in range(view["n_segs"]):
-        sl = view["segwave_slice"][ptr[g * NW]:ptr[(g + 1) * NW]]
-        assert sl.size > 0 and (view["slice_block"][sl] == view["seg_block"][g]).all()
+        assert (view["slice_block"][ptr[g]:ptr[g + 1]] == view["seg_block"][g]).all()
+        assert np.all(np.diff(view["slice_width"][ptr[g]:ptr[g + 1]]) <= 0)
     return A
 
 
-def wave_balance(view, c0=10):
-    """(mean over workgroups of critical path, ideal per-wave cost): how evenly the waves are loaded."""
-    NW = view["n_waves"]
-    ptr = view["segwave_ptr"]
+def workgroup_balance(view, c0=10):
+    """Cost (entries per lane + c0 per slice) of every workgroup's share: how evenly the persistent workgroups are loaded."""
+    ptr = view["seg_ptr"]
     w = view["slice_width"].astype(np.int64) + c0
-    crit, tot = [], []
-    for g in range(view["n_wg"]):
-        c = t = 0
-        for sg in range(view["wg_seg0"][g], view["wg_seg0"][g + 1]):
-            per = [w[view["segwave_slice"][ptr[sg * NW + v]:ptr[sg * NW + v + 1]]].sum() for v in range(NW)]
-            c += max(per); t += sum(per)
-        crit.append(c); tot.append(t)
-    return np.array(crit), np.array(tot) / NW
+    return np.array([w[ptr[view["wg_seg0"][g]]:ptr[view["wg_seg0"][g + 1]]].sum() for g in range(view["n_wg"])])
