@@ -38,6 +38,7 @@ class LayoutView(ctypes.Structure):
         ("side", ctypes.c_int32), ("wide", ctypes.c_int32),
         ("n_major", ctypes.c_int64), ("n_minor", ctypes.c_int64),
         ("block_width", ctypes.c_int32), ("n_blocks", ctypes.c_int32), ("max_len", ctypes.c_int32), ("n_wg", ctypes.c_int32),
+        ("row_slots", ctypes.c_int32),
         ("n_tasks", ctypes.c_int64), ("n_slices", ctypes.c_int64), ("n_slots", ctypes.c_int64), ("n_segs", ctypes.c_int64),
         ("task_major", c_uint32_p), ("slice_width", c_int32_p), ("slice_off", c_int64_p), ("slice_block", c_int32_p),
         ("seg_block", c_int32_p), ("wg_seg0", c_int32_p), ("seg_ptr", c_int32_p),

@@ -28,7 +28,7 @@ struct Matrix {
     std::vector<int64_t> colptr;   // m+1
     std::vector<int32_t> row;      // nnz
     std::vector<double> val;       // nnz
-    bool counts_u16 = false;       // every stored value is an integer in [1, 65535]
+    bool counts_u16 = false;       // every stored value is an integer in [1, kPackedCountMax]: the 4-byte entry format applies
 };
 
 // sum over stored entries of lgamma(x+1) for columns [cb, ce), fixed summation order.
@@ -52,12 +52,17 @@ constexpr int kLanes = 64;          // one slice = one wavefront
 constexpr int kUnroll = 4;          // entries per lane per 16-byte load
 constexpr int kWidthQuantum = 8;    // slice widths are multiples of this (two loads per loop trip)
 constexpr uint32_t kIdleLane = 0xFFFFFFFFu;
+// Packed entry word: bits 4..17 = the LDS slot (16-byte unit) of the minor's factor row, already shifted into a
+// byte offset (word & kPackedOffsetMask); bits 18..31 = the count.  Padding slots are 0 (row 0, count 0).
+constexpr int kPackedCountShift = 18;
+constexpr uint32_t kPackedOffsetMask = 0x3FFF0u;
+constexpr double kPackedCountMax = 16383.0;
 
 struct Layout {
     int side = 0;                   // 0: lanes own genes, minors = cells; 1: lanes own cells, minors = genes
     bool wide = false;
     int64_t n_major = 0, n_minor = 0;
-    int32_t block_width = 0, n_blocks = 0, max_len = 0, n_wg = 0;
+    int32_t block_width = 0, n_blocks = 0, max_len = 0, n_wg = 0, row_slots = 0;
     int64_t n_tasks = 0, n_slices = 0, n_slots = 0, n_segs = 0, nnz = 0;
     std::vector<uint32_t> task_major;    // n_slices * 64 ; kIdleLane pads a block's last slice
     std::vector<int32_t> slice_width;    // n_slices ; entries per lane, multiple of 4
@@ -77,6 +82,7 @@ struct LayoutParams {
     int32_t block_width;   // minors per LDS block
     int32_t max_len;       // longest task (entries), multiple of 4
     int32_t n_wg;          // persistent workgroups of the sweep kernel
+    int32_t row_slots;     // 16-byte LDS slots per staged factor row at this rank (lds_row_bytes / 16)
 };
 
 // Padded rank used on the device (even, so a factor row is a whole number of 16-byte LDS reads).

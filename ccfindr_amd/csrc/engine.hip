@@ -149,17 +149,27 @@ SweepSide sweep_side_args(const vbnmf_engine *e, const DeviceSide &S, bool gene_
     return P;
 }
 
+// First use of a sweep kernel on a device: allow the 160 KB dynamic LDS image, and make sure the kernel has no
+// static LDS in front of it -- lds_row() (kernels.h) addresses the staged block from LDS address 0.
+int prepare_sweep_kernel(const void *fn)
+{
+    HIPCHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipFuncAttributes fa;
+    HIPCHECK(hipFuncGetAttributes(&fa, fn));
+    if (fa.sharedSizeBytes != 0)
+        return fail(VBNMF_ERR_HIP, "sweep kernel carries %zu bytes of static LDS; its dynamic LDS would not start at 0", (size_t)fa.sharedSizeBytes);
+    return VBNMF_OK;
+}
+
 // ---- dispatch over the padded rank (compile-time so factor rows live in registers) ----
 template <int R, bool WIDE, int NT>
 int launch_sweep_t(vbnmf_engine *e, const SweepSide &a, const SweepSide &b)
 {
     static bool attr_set[16] = {false};
     const void *fn = (const void *)k_sweep<R, WIDE, NT>;
-    if (e->device < 16 && !attr_set[e->device]) {
-        HIPCHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set[e->device] = true;
-    } else if (e->device >= 16) {
-        HIPCHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    if (e->device >= 16 || !attr_set[e->device]) {
+        if (int rc = prepare_sweep_kernel(fn)) return rc;
+        if (e->device < 16) attr_set[e->device] = true;
     }
     const unsigned grid = (unsigned)e->n_wg;
     hipLaunchKernelGGL((k_sweep<R, WIDE, NT>), dim3(grid), dim3(NT), e->lds_bytes, e->stream, a, b);
@@ -272,7 +282,7 @@ int launch_sweep1_t(vbnmf_engine *e, const SweepSide &a)
     static bool attr_set[16] = {false};
     const void *fn = (const void *)k_sweep1<R, WIDE, LOGTERM, NT>;
     if (e->device >= 16 || !attr_set[e->device]) {
-        HIPCHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        if (int rc = prepare_sweep_kernel(fn)) return rc;
         if (e->device < 16) attr_set[e->device] = true;
     }
     hipLaunchKernelGGL((k_sweep1<R, WIDE, LOGTERM, NT>), dim3((unsigned)e->n_wg), dim3(NT), e->lds_bytes, e->stream, a);

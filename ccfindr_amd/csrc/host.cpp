@@ -78,7 +78,7 @@ static void finish_matrix(Matrix &X)
     bool ok = true;
     for (int64_t e = 0; e < X.nnz && ok; e++) {
         double v = X.val[e];
-        ok = (v >= 1.0 && v <= 65535.0 && v == std::floor(v));
+        ok = (v >= 1.0 && v <= kPackedCountMax && v == std::floor(v));
     }
     X.counts_u16 = ok;
 }
@@ -293,13 +293,15 @@ LayoutParams default_layout_params(int64_t n_major, int64_t n_minor, int R, int 
     if (n_wg <= 0) n_wg = env_int("VBNMF_NWG", 256);
     if (n_wg < 1) n_wg = 1;
     lp.n_wg = n_wg;
+    lp.row_slots = lds_row_bytes(R) / 16;
     return lp;
 }
 
 int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const LayoutParams &lp, Layout &L)
 {
     if (cb < 0 || ce > X.m || cb >= ce) return fail(VBNMF_ERR_BAD_ARG, "column range [%lld, %lld) is outside the matrix", (long long)cb, (long long)ce);
-    if (lp.block_width <= 0 || lp.block_width > 65536 || lp.max_len <= 0 || lp.max_len % kWidthQuantum || lp.n_wg <= 0)
+    if (lp.block_width <= 0 || lp.block_width > 65536 || lp.max_len <= 0 || lp.max_len % kWidthQuantum || lp.n_wg <= 0 || lp.row_slots <= 0 ||
+        (int64_t)lp.block_width * lp.row_slots > (int64_t)(kPackedOffsetMask >> 4) + 1)
         return fail(VBNMF_ERR_BAD_ARG, "bad layout parameters");
 
     // major-compressed view of X[:, cb:ce)
@@ -322,6 +324,7 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
     L.block_width = lp.block_width;
     L.max_len = lp.max_len;
     L.n_wg = lp.n_wg;
+    L.row_slots = lp.row_slots;
     const int64_t nmaj = L.n_major;
     const int32_t C = L.block_width;
     const int32_t nblk = (int32_t)((L.n_minor + C - 1) / C);
@@ -568,7 +571,7 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
                 int64_t slot = so + (t / kUnroll) * (kLanes * kUnroll) + lane * kUnroll + (t % kUnroll);
                 uint32_t local = (uint32_t)(idx[q] - m0);
                 if (L.wide) { L.wide_idx[slot] = local; L.wide_val[slot] = val[q]; }
-                else L.packed[slot] = ((uint32_t)val[q] << 16) | local;
+                else L.packed[slot] = ((uint32_t)val[q] << kPackedCountShift) | ((local * (uint32_t)L.row_slots) << 4);
             };
             if (!schedule) {
                 for (int lane = 0; lane < kLanes; lane++) {
@@ -759,7 +762,7 @@ int vbnmf_layout_build(const vbnmf_matrix *X, int64_t col_begin, int64_t col_end
     view->task_major = L.task_major.data(); view->slice_width = L.slice_width.data();
     view->slice_off = L.slice_off.data(); view->slice_block = L.slice_block.data();
     view->seg_block = L.seg_block.data(); view->wg_seg0 = L.wg_seg0.data();
-    view->seg_ptr = L.seg_ptr.data();
+    view->seg_ptr = L.seg_ptr.data(); view->row_slots = L.row_slots;
     view->inv_ptr = L.inv_ptr.data(); view->inv_task = L.inv_task.data();
     view->packed = L.wide ? nullptr : L.packed.data();
     view->wide_idx = L.wide ? L.wide_idx.data() : nullptr;

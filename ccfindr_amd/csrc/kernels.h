@@ -35,7 +35,7 @@ constexpr uint32_t kIdle = 0xFFFFFFFFu;
 // statistics are written task-major (a wave writes one contiguous 64*R*8-byte piece).
 // ------------------------------------------------------------------------------------
 struct SweepSide {
-    const uint32_t *packed;        // (count << 16) | local minor          (packed layout)
+    const uint32_t *packed;        // (count << 18) | (LDS slot of the minor's row << 4)   (packed layout, common.h)
     const uint32_t *widx;          // local minor                           (wide layout)
     const double *wval;            // value                                 (wide layout)
     const uint32_t *task_major;    // [n_slices][64]
@@ -65,18 +65,6 @@ struct SweepRegs {
     double lsum;
 };
 
-// One row (R doubles) of the staged factor block, by byte offset into the LDS image.
-template <int R>
-__device__ __forceinline__ void lds_row(const double2 *__restrict__ ldsG, uint32_t byte_off, double2 (&gv)[R / 2])
-{
-#if defined(VBNMF_ABLATE_LDS_BCAST)
-    byte_off = 0;                                          // every lane reads row 0: pure broadcast, no conflicts
-#endif
-    const double2 *g = reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(ldsG) + byte_off);
-#pragma unroll
-    for (int kk = 0; kk < R / 2; kk++) gv[kk] = g[kk];
-}
-
 // A 4-entry group of the packed stream, unpacked: LDS byte offset of the minor's row and the count.
 // The loop carries these (not the raw words) from one trip to the next: the unpacking is work
 // the trip needs anyway, and a loop-carried value that is not a bare load result cannot be
@@ -98,14 +86,31 @@ constexpr int kLdsEvSlots = 256;
 constexpr uint32_t kLdsEvBase = kLdsTabBytes;
 constexpr uint32_t kLdsCtrBase = kLdsEvBase + kLdsEvSlots * sizeof(double);
 constexpr uint32_t kLdsRowBase = kLdsCtrBase + 16;
+// One row (R doubles) of the staged factor block, by byte offset into the block.  The sweep kernels own no static
+// LDS, so their dynamic LDS starts at address 0 (launch_sweep_t checks it) and the row address is the offset itself
+// plus kLdsRowBase, a constant the ds_read instructions carry in their immediate: no VALU address arithmetic.
+template <int R>
+__device__ __forceinline__ void lds_row(const double2 *__restrict__ ldsG, uint32_t byte_off, double2 (&gv)[R / 2])
+{
+#if defined(VBNMF_ABLATE_LDS_BCAST)
+    byte_off = 0;                                          // every lane reads row 0: pure broadcast, no conflicts
+#endif
+    (void)ldsG;
+    typedef double __attribute__((ext_vector_type(2))) Pair;
+    typedef const __attribute__((address_space(3))) Pair LdsPair;
+    LdsPair *g = reinterpret_cast<LdsPair *>(static_cast<uintptr_t>(byte_off + kLdsRowBase));
+#pragma unroll
+    for (int kk = 0; kk < R / 2; kk++) { const Pair v = g[kk]; gv[kk] = make_double2(v.x, v.y); }
+}
+
 template <int R>
 __device__ __forceinline__ Group4 unpack4(const uint4 e)
 {
-    constexpr uint32_t kRow = ((R / 2) | 1) * 16;          // LDS row stride: odd number of 16-byte slots
+    // the word carries the row's byte offset inside the staged block (one AND) and the count (one shift), common.h
     Group4 g;
-    g.o0 = (e.x & 0xFFFFu) * kRow + kLdsRowBase; g.o1 = (e.y & 0xFFFFu) * kRow + kLdsRowBase;
-    g.o2 = (e.z & 0xFFFFu) * kRow + kLdsRowBase; g.o3 = (e.w & 0xFFFFu) * kRow + kLdsRowBase;
-    g.c0 = e.x >> 16; g.c1 = e.y >> 16; g.c2 = e.z >> 16; g.c3 = e.w >> 16;
+    g.o0 = e.x & 0x3FFF0u; g.o1 = e.y & 0x3FFF0u;
+    g.o2 = e.z & 0x3FFF0u; g.o3 = e.w & 0x3FFF0u;
+    g.c0 = e.x >> 18; g.c1 = e.y >> 18; g.c2 = e.z >> 18; g.c3 = e.w >> 18;
     return g;
 }
 
@@ -128,7 +133,7 @@ __device__ __forceinline__ void sweep_entry(SweepRegs<R> &S, const double2 *__re
 #if defined(VBNMF_ABLATE_NODIV)
     const double q = x * wth;
 #else
-    const double q = dev_div(x, wth);
+    const double q = dev_div_fast(x, wth);
 #endif
 #pragma unroll
     for (int kk = 0; kk < R / 2; kk++) {
@@ -266,12 +271,12 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
                 for (int g = 0; g < ng; g++) {
                     const uint4 c = E[(size_t)g * 64];
                     const double2 v0 = V[(size_t)g * 128], v1 = V[(size_t)g * 128 + 1];
-                    lds_row<R>(ldsG, c.x * (((R / 2) | 1) * 16) + kLdsRowBase, g0);
-                    lds_row<R>(ldsG, c.y * (((R / 2) | 1) * 16) + kLdsRowBase, g1);
+                    lds_row<R>(ldsG, c.x * (((R / 2) | 1) * 16), g0);
+                    lds_row<R>(ldsG, c.y * (((R / 2) | 1) * 16), g1);
                     sweep_entry<R>(T, ldsG, g0, v0.x, LOGTERM);
-                    lds_row<R>(ldsG, c.z * (((R / 2) | 1) * 16) + kLdsRowBase, g0);
+                    lds_row<R>(ldsG, c.z * (((R / 2) | 1) * 16), g0);
                     sweep_entry<R>(T, ldsG, g1, v0.y, LOGTERM);
-                    lds_row<R>(ldsG, c.w * (((R / 2) | 1) * 16) + kLdsRowBase, g1);
+                    lds_row<R>(ldsG, c.w * (((R / 2) | 1) * 16), g1);
                     sweep_entry<R>(T, ldsG, g0, v1.x, LOGTERM);
                     sweep_entry<R>(T, ldsG, g1, v1.y, LOGTERM);
                 }

@@ -59,6 +59,16 @@ __host__ __device__ __forceinline__ double dev_div(double x, double w)
     return fma(fma(-w, q, x), rc, q);
 }
 
+// x / w to 2^-48 relative (one-sided: the result is (x/w)(1 - e^2), e = the seed's relative error <= 2^-24.4):
+// seed, quotient, ONE residual correction -- 3 fp64 operations after the seed instead of 5.  For the sweep's
+// q = x / wth, whose consumers are sums held to 1e-12.
+__host__ __device__ __forceinline__ double dev_div_fast(double x, double w)
+{
+    const double rc = sp_rcp_seed(w);
+    const double q = x * rc;
+    return fma(fma(-w, q, x), rc, q);
+}
+
 // ---- table-driven ln for the sweep's inner loop ------------------------------------------
 // x = m 2^k, m in [0.5, 1) cut into 128 intervals; per interval c = 1/midpoint (rounded) and
 // -ln(c); r = m c - 1 is exact in one fma and |r| <= 2^-8, so

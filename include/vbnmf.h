@@ -243,12 +243,13 @@ int vbnmf_ml_update_csc(int64_t n, int64_t m, int32_t r, const int32_t *p, const
  * --------------------------------------------------------------------------------- */
 typedef struct vbnmf_layout vbnmf_layout;
 typedef struct {
-    int32_t side, wide;            /* wide: 0 = packed u16 index | u16 count, 1 = u32 index + f64 value */
+    int32_t side, wide;            /* wide: 0 = 4-byte entries (integer counts <= 16383), 1 = u32 index + f64 value */
     int64_t n_major, n_minor;      /* lanes own majors; minors are gathered from LDS */
     int32_t block_width;           /* minors per LDS block */
     int32_t n_blocks;              /* ceil(n_minor / block_width) */
     int32_t max_len;               /* longest task (entries per lane) */
     int32_t n_wg;                  /* persistent workgroups the work list is cut for */
+    int32_t row_slots;             /* 16-byte LDS slots per staged factor row at this rank */
     int64_t n_tasks, n_slices;     /* task = run of one major's entries in one block; slice = 64 tasks */
     int64_t n_slots;               /* padded entry slots (all slices) */
     int64_t n_segs;                /* segment = the slices of one block in one workgroup's share */
@@ -262,7 +263,7 @@ typedef struct {
     const int32_t *seg_ptr;        /* [n_segs+1] first slice of each segment; slices are numbered in processing order */
     const int32_t *inv_ptr;        /* [n_major+1] tasks of each major ... */
     const uint32_t *inv_task;      /* [n_tasks]   ... in the order their partials are summed */
-    const uint32_t *packed;        /* [n_slots] (count << 16) | local minor    (wide == 0) */
+    const uint32_t *packed;        /* [n_slots] (count << 18) | (local minor * row_slots << 4)   (wide == 0) */
     const uint32_t *wide_idx;      /* [n_slots] local minor                    (wide == 1) */
     const double *wide_val;        /* [n_slots]                                (wide == 1) */
 } vbnmf_layout_view;

@@ -15,7 +15,7 @@ def build_layout(M, side, r, cols=None):
     N.check(L.vbnmf_layout_build(M._h, cb, ce, side, r, ctypes.byref(h), ctypes.byref(v)))
     try:
         out = {k: getattr(v, k) for k in ("side", "wide", "n_major", "n_minor", "block_width", "n_blocks", "max_len",
-                                          "n_wg", "n_tasks", "n_slices", "n_slots", "n_segs")}
+                                          "n_wg", "row_slots", "n_tasks", "n_slices", "n_slots", "n_segs")}
         arr = lambda p, cnt: np.ctypeslib.as_array(p, shape=(cnt,)).copy() if cnt else np.zeros(0, dtype=np.int64)
         out["task_major"] = arr(v.task_major, v.n_slices * 64)
         out["slice_width"] = arr(v.slice_width, v.n_slices)
@@ -56,7 +56,7 @@ def reconstruct(view):
                 idx, val = view["wide_idx"][slots], view["wide_val"][slots]
             else:
                 e = view["packed"][slots]
-                idx, val = e & 0xFFFF, (e >> 16).astype(np.float64)
+                idx, val = ((e >> 4) & 0x3FFF) // view["row_slots"], (e >> 18).astype(np.float64)
             if M == 0xFFFFFFFF:
                 assert not val.any() and not idx.any()
                 lens.append(0)
