@@ -150,25 +150,25 @@ def hyper_update(hyper_update, wh, hyper, Niter=100, Tol=1e-4):
     return {"aw": aw1, "bw": bw1, "ah": ah1, "bh": bh1}
 
 
-def vb_init(nrow, ncol, mat, rank, hyper, initializer, max=1.0, rng=None):
+def vb_init(nrow, ncol, mat, rank, hyper, initializer, max=1.0, rng=None, device=0):
     """Initial ``wh``; reference R/bayesian.R:109-171.  ``random`` draws from the Gamma priors
     with a numpy Generator (R's RNG stream cannot be reproduced outside R); ``svd2`` takes
-    |U| and |D V^T| of a rank-``rank`` SVD rescaled so mean(h) = bh."""
+    |U| and |D V^T| of a rank-``rank`` SVD rescaled so mean(h) = bh -- the full SVD on the host for small
+    matrices, as the reference does (:151-152), otherwise the truncated one on the device
+    (``ccfindr_amd.linalg.truncated_svd`` in place of irlba, :154); ``svd`` is the NNDSVD-like start (:116-149)."""
     if initializer == "random":
         if rng is None:
             rng = np.random.default_rng()
         w = rng.gamma(shape=hyper["aw"], scale=hyper["bw"] / hyper["aw"], size=(nrow, rank))   # :112-113
         h = rng.gamma(shape=hyper["ah"], scale=hyper["bh"] / hyper["ah"], size=(rank, ncol))   # :114-115
     elif initializer == "svd2":
-        if min(nrow, ncol) / 2 <= rank or not hasattr(mat, "tocsc"):
+        if min(nrow, ncol) / 2 <= rank and not isinstance(mat, CountMatrix):
             A = mat.toarray() if hasattr(mat, "toarray") else np.asarray(mat, dtype=np.float64)
             u, d, vt = np.linalg.svd(A, full_matrices=False)                                    # :152
             u, d, vt = u[:, :rank], d[:rank], vt[:rank]
         else:
-            from scipy.sparse.linalg import svds
-            u, d, vt = svds(mat.astype(np.float64), k=rank)                                     # :154 (irlba)
-            o = np.argsort(-d)
-            u, d, vt = u[:, o], d[o], vt[o]
+            from .linalg import truncated_svd                                                   # :154 (irlba), on the device
+            u, d, vt = truncated_svd(mat, rank, seed=0 if rng is None else int(rng.integers(1 << 31)), device=device)
         w = np.abs(u)                                                                           # :155
         h = np.abs(np.diag(d) @ vt)                                                             # :156
         scale = hyper["bh"] / np.mean(h)                                                        # :157
@@ -245,7 +245,9 @@ def vb_run_rank(irun, rank, bundle):
     ga, gb = np.atleast_1d(bundle["gamma_a"]), np.atleast_1d(bundle["gamma_b"])
     hyper = {"aw": float(ga[0]), "ah": float(ga[-1]), "bw": float(gb[0]), "bh": float(gb[-1])}   # :321-326
     rng = _bundle_rng(bundle, irun, rank)
-    wh0 = vb_init(nrow, ncol, bundle.get("raw"), rank, hyper=hyper, initializer=bundle["initializer"], rng=rng)
+    raw = bundle.get("raw")
+    wh0 = vb_init(nrow, ncol, raw if raw is not None else X, rank, hyper=hyper, initializer=bundle["initializer"], rng=rng,
+                  device=bundle.get("device", 0))
     eng = _make_engine(bundle, rank)
     try:
         eng.set_state(wh0["lw"], wh0["lh"], wh0["eh"])

@@ -349,6 +349,28 @@ int launch_ml_final(vbnmf_engine *e)
     return VBNMF_OK;
 }
 
+// ---- sparse products on the tiled layout (k_spmm) ----
+template <int R, bool WIDE, int NT>
+int launch_spmm_t(vbnmf_engine *e, const SweepSide &a)
+{
+    static bool attr_set[16] = {false};
+    const void *fn = (const void *)k_spmm<R, WIDE, NT>;
+    if (e->device >= 16 || !attr_set[e->device]) {
+        if (int rc = prepare_sweep_kernel(fn)) return rc;
+        if (e->device < 16) attr_set[e->device] = true;
+    }
+    hipLaunchKernelGGL((k_spmm<R, WIDE, NT>), dim3((unsigned)e->n_wg), dim3(NT), e->lds_bytes, e->stream, a);
+    HIPCHECK(hipGetLastError());
+    return VBNMF_OK;
+}
+
+template <int R>
+int launch_spmm_r(vbnmf_engine *e, const SweepSide &a)
+{
+    constexpr int NT = sweep_threads(R);
+    return e->wide ? launch_spmm_t<R, true, NT>(e, a) : launch_spmm_t<R, false, NT>(e, a);
+}
+
 // Wait for k_final's sequence flag in pinned memory; falls back to the stream if it takes long.
 int wait_result(vbnmf_engine *e)
 {
@@ -906,6 +928,48 @@ int vbnmf_engine_ml_get_state(vbnmf_engine *e, double *w, double *h)
         }
     } catch (const std::bad_alloc &) {
         return fail(VBNMF_ERR_OOM, "out of host memory staging the state");
+    }
+    return VBNMF_OK;
+}
+
+// ---------------------------------------------------------------- sparse products (truncated SVD of the svd2 initialiser)
+int vbnmf_engine_spmm(vbnmf_engine *e, int32_t transpose, const double *B, double *C)
+{
+    if (!e || !B || !C) return fail(VBNMF_ERR_BAD_ARG, "NULL argument");
+    if (e->partitioned) return fail(VBNMF_ERR_STATE, "spmm needs an unpartitioned engine");
+    if (int rc = use_device(e)) return rc;
+    // the factor arrays serve as operand storage: whatever state the engine held is gone
+    e->has_state = false; e->stats_ready = false; e->step_pending = false; e->prime_pending = false; e->ml_ready = false;
+    const bool gene_side = transpose == 0;             // C = X t(B): lanes own genes and gather rows of B (one per cell)
+    const int64_t n_in = gene_side ? e->m : e->n, n_out = gene_side ? e->n : e->m;
+    double *operand = gene_side ? e->lh : e->lw;       // gathered through LDS
+    double *dense = gene_side ? e->ew : e->eh;         // [n_out][R] result before the download
+    try {
+        std::vector<double> tmp;
+        to_index_major(B, n_in, e->r, e->R, gene_side, tmp);
+        HIPCHECK(hipMemcpyAsync(operand, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
+        HIPCHECK(hipStreamSynchronize(e->stream));
+        SweepSide a = sweep_side_args(e, gene_side ? e->A : e->B, gene_side, gene_side ? e->epart : e->epart + e->n_wg);
+        a.logterm = 0;
+        a.stop = nullptr;
+        int rc = VBNMF_ERR_BAD_ARG;
+        switch (e->R) {
+#define X(RR) case RR: rc = launch_spmm_r<RR>(e, a); break;
+            VBNMF_FOR_EACH_R(X)
+#undef X
+            default: return fail(VBNMF_ERR_BAD_ARG, "unsupported padded rank %d", e->R);
+        }
+        if (rc) return rc;
+        const DeviceSide &S = gene_side ? e->A : e->B;
+        const int64_t cnt = n_out * e->R;
+        hipLaunchKernelGGL(k_pack, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, e->stream, S.part, S.inv_ptr, S.inv_task, n_out, e->R, dense);
+        HIPCHECK(hipGetLastError());
+        tmp.resize((size_t)cnt);
+        HIPCHECK(hipMemcpyAsync(tmp.data(), dense, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+        HIPCHECK(hipStreamSynchronize(e->stream));
+        from_index_major(tmp, n_out, e->r, e->R, !gene_side, C);
+    } catch (const std::bad_alloc &) {
+        return fail(VBNMF_ERR_OOM, "out of host memory staging the operands");
     }
     return VBNMF_OK;
 }

@@ -118,10 +118,20 @@ __device__ __forceinline__ Group4 unpack4(const uint4 e)
 // Padding slots have x = 0 and minor 0 of the block: they add exact zeros as long as wth
 // there is finite and non-zero.  It can only fail to be when a whole factor row is 0 or
 // non-finite, and then the reference's dense X/wth (src/vbnmf_update.cpp:34) is NaN as well.
-template <int R>
+// SPMM: the plain product instead (acc += x g: no ratio, no logarithm) -- k_spmm, for the truncated SVD of the
+// svd2 initialiser.
+template <int R, bool SPMM = false>
 __device__ __forceinline__ void sweep_entry(SweepRegs<R> &S, const double2 *__restrict__ ldsG, const double2 (&gv)[R / 2],
                                             double x, bool logterm)
 {
+    if (SPMM) {
+#pragma unroll
+        for (int kk = 0; kk < R / 2; kk++) {
+            S.acc[2 * kk] = fma(x, gv[kk].x, S.acc[2 * kk]);
+            S.acc[2 * kk + 1] = fma(x, gv[kk].y, S.acc[2 * kk + 1]);
+        }
+        return;
+    }
     // two interleaved partial sums (even / odd k): half the dependent-chain length
     double w0 = S.F[0] * gv[0].x, w1 = S.F[1] * gv[0].y;
 #pragma unroll
@@ -158,7 +168,8 @@ __device__ __attribute__((noinline)) int take_ticket(int *ticket)
 }
 
 // EV selects the per-slice scalar left in the evidence slots: 1 = the VB data term sum(acc . llF) - sum x log(wth)
-// (see the header), 2 = sum x log(wth) alone (ML-NMF likelihood, mlnmf.h), 0 = nothing.
+// (see the header), 2 = sum x log(wth) alone (ML-NMF likelihood, mlnmf.h), 0 = nothing, 3 = nothing and the entries
+// are accumulated as a plain sparse product (k_spmm).
 template <int R, bool WIDE, bool LOGTERM, int NT, int EV = 1>
 __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restrict__ ldsG)
 {
@@ -226,10 +237,10 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
                 const uint4 *E = reinterpret_cast<const uint4 *>(S.packed + off) + lane;
                 for (int g = 0; g < ng; g++) {
                     const Group4 a = unpack4<R>(E[(size_t)g * 64]);
-                    lds_row<R>(ldsG, a.o0, g0); sweep_entry<R>(T, ldsG, g0, (double)a.c0, LOGTERM);
-                    lds_row<R>(ldsG, a.o1, g0); sweep_entry<R>(T, ldsG, g0, (double)a.c1, LOGTERM);
-                    lds_row<R>(ldsG, a.o2, g0); sweep_entry<R>(T, ldsG, g0, (double)a.c2, LOGTERM);
-                    lds_row<R>(ldsG, a.o3, g0); sweep_entry<R>(T, ldsG, g0, (double)a.c3, LOGTERM);
+                    lds_row<R>(ldsG, a.o0, g0); sweep_entry<R, EV == 3>(T, ldsG, g0, (double)a.c0, LOGTERM);
+                    lds_row<R>(ldsG, a.o1, g0); sweep_entry<R, EV == 3>(T, ldsG, g0, (double)a.c1, LOGTERM);
+                    lds_row<R>(ldsG, a.o2, g0); sweep_entry<R, EV == 3>(T, ldsG, g0, (double)a.c2, LOGTERM);
+                    lds_row<R>(ldsG, a.o3, g0); sweep_entry<R, EV == 3>(T, ldsG, g0, (double)a.c3, LOGTERM);
                 }
             } else if (!WIDE) {
                 double2 g1[R / 2];
@@ -243,23 +254,23 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
                     const int pn = min(p + 1, np - 1);                    // last trip re-reads itself
                     const uint4 ec = E[(size_t)pn * 128], ed = E[(size_t)pn * 128 + 64];
                     lds_row<R>(ldsG, a.o1, g1); VBNMF_FENCE();
-                    sweep_entry<R>(T, ldsG, g0, (double)a.c0, LOGTERM); VBNMF_FENCE();
+                    sweep_entry<R, EV == 3>(T, ldsG, g0, (double)a.c0, LOGTERM); VBNMF_FENCE();
                     lds_row<R>(ldsG, a.o2, g0); VBNMF_FENCE();
-                    sweep_entry<R>(T, ldsG, g1, (double)a.c1, LOGTERM); VBNMF_FENCE();
+                    sweep_entry<R, EV == 3>(T, ldsG, g1, (double)a.c1, LOGTERM); VBNMF_FENCE();
                     lds_row<R>(ldsG, a.o3, g1); VBNMF_FENCE();
-                    sweep_entry<R>(T, ldsG, g0, (double)a.c2, LOGTERM); VBNMF_FENCE();
+                    sweep_entry<R, EV == 3>(T, ldsG, g0, (double)a.c2, LOGTERM); VBNMF_FENCE();
                     lds_row<R>(ldsG, b.o0, g0); VBNMF_FENCE();
-                    sweep_entry<R>(T, ldsG, g1, (double)a.c3, LOGTERM); VBNMF_FENCE();
+                    sweep_entry<R, EV == 3>(T, ldsG, g1, (double)a.c3, LOGTERM); VBNMF_FENCE();
                     lds_row<R>(ldsG, b.o1, g1); VBNMF_FENCE();
-                    sweep_entry<R>(T, ldsG, g0, (double)b.c0, LOGTERM); VBNMF_FENCE();
+                    sweep_entry<R, EV == 3>(T, ldsG, g0, (double)b.c0, LOGTERM); VBNMF_FENCE();
                     lds_row<R>(ldsG, b.o2, g0); VBNMF_FENCE();
-                    sweep_entry<R>(T, ldsG, g1, (double)b.c1, LOGTERM); VBNMF_FENCE();
+                    sweep_entry<R, EV == 3>(T, ldsG, g1, (double)b.c1, LOGTERM); VBNMF_FENCE();
                     lds_row<R>(ldsG, b.o3, g1); VBNMF_FENCE();
-                    sweep_entry<R>(T, ldsG, g0, (double)b.c2, LOGTERM); VBNMF_FENCE();
+                    sweep_entry<R, EV == 3>(T, ldsG, g0, (double)b.c2, LOGTERM); VBNMF_FENCE();
                     a = unpack4<R>(ec);
                     pin(a);
                     lds_row<R>(ldsG, a.o0, g0); VBNMF_FENCE();
-                    sweep_entry<R>(T, ldsG, g1, (double)b.c3, LOGTERM); VBNMF_FENCE();
+                    sweep_entry<R, EV == 3>(T, ldsG, g1, (double)b.c3, LOGTERM); VBNMF_FENCE();
                     b = unpack4<R>(ed);
                     pin(b);
                 }
@@ -273,12 +284,12 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
                     const double2 v0 = V[(size_t)g * 128], v1 = V[(size_t)g * 128 + 1];
                     lds_row<R>(ldsG, c.x * (((R / 2) | 1) * 16), g0);
                     lds_row<R>(ldsG, c.y * (((R / 2) | 1) * 16), g1);
-                    sweep_entry<R>(T, ldsG, g0, v0.x, LOGTERM);
+                    sweep_entry<R, EV == 3>(T, ldsG, g0, v0.x, LOGTERM);
                     lds_row<R>(ldsG, c.z * (((R / 2) | 1) * 16), g0);
-                    sweep_entry<R>(T, ldsG, g1, v0.y, LOGTERM);
+                    sweep_entry<R, EV == 3>(T, ldsG, g1, v0.y, LOGTERM);
                     lds_row<R>(ldsG, c.w * (((R / 2) | 1) * 16), g1);
-                    sweep_entry<R>(T, ldsG, g0, v1.x, LOGTERM);
-                    sweep_entry<R>(T, ldsG, g1, v1.y, LOGTERM);
+                    sweep_entry<R, EV == 3>(T, ldsG, g0, v1.x, LOGTERM);
+                    sweep_entry<R, EV == 3>(T, ldsG, g1, v1.y, LOGTERM);
                 }
             }
 
@@ -340,6 +351,16 @@ __global__ __launch_bounds__(NT) void k_sweep1(const SweepSide S)
 {
     extern __shared__ double2 ldsG[];
     sweep_side<R, WIDE, LOGTERM, NT, LOGTERM ? 2 : 0>(S, ldsG);
+}
+
+// Sparse product on the tiled layout (the truncated SVD behind the svd2 initialiser,
+// reference R/bayesian.R:150-159 irlba): per task sum_minor x * G[minor, :] -- X G on the gene side, t(X) G on the
+// cell side -- into the same per-task partials, which k_pack then sums per major.
+template <int R, bool WIDE, int NT>
+__global__ __launch_bounds__(NT) void k_spmm(const SweepSide S)
+{
+    extern __shared__ double2 ldsG[];
+    sweep_side<R, WIDE, false, NT, 3>(S, ldsG);
 }
 
 // Sum of one major's task partials for column k, in the inverse index's fixed order.  The

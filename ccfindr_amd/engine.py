@@ -205,6 +205,21 @@ class VBEngine:
         N.check(self._lib.vbnmf_engine_ml_get_state(self._h, N.dptr(w), N.dptr(h)))
         return {k: v for k, v in (("ew", w), ("eh", h)) if v is not None}
 
+    # -- sparse products with the resident X (truncated SVD of the svd2 initialiser) ----------
+    def spmm(self, B, transpose=False):
+        """``X @ B.T`` (B: r x m -> n x r) or, with ``transpose``, ``B.T @ X`` (B: n x r -> r x m); drops any state."""
+        B = N.fcol(B)
+        if not transpose:
+            if B.shape != (self.rank, self.m):
+                raise ValueError(f"B must be {(self.rank, self.m)}")
+            out = np.empty((self.n, self.rank), order="F")
+        else:
+            if B.shape != (self.n, self.rank):
+                raise ValueError(f"B must be {(self.n, self.rank)}")
+            out = np.empty((self.rank, self.m), order="F")
+        N.check(self._lib.vbnmf_engine_spmm(self._h, int(bool(transpose)), N.dptr(B), N.dptr(out)))
+        return out
+
     def run(self, hyper, Itmax=10000, Tol=1e-5, n0=10, dn=1, flags=(True,) * 4, fudge=EPS, history=False):
         """The per-rank loop of vb_iterate (reference R/bayesian.R:336-352) driven by the device.
 

@@ -236,6 +236,17 @@ int vbnmf_ml_update_csc(int64_t n, int64_t m, int32_t r, const int32_t *p, const
                         double *w, double *h, double *lk);
 
 /* ---------------------------------------------------------------------------------
+ * Sparse products with the resident X, the two matrix-vector
+ * blocks of a truncated SVD -- what irlba::irlba(mat, rank) computes for the svd2
+ * initialiser (R/bayesian.R:150-159) -- on the same tiled layout as the update sweeps:
+ *   transpose == 0 :  C (n x r) = X %*% t(B),   B : r x m  (column-major, like h)
+ *   transpose != 0 :  C (r x m) = t(B) %*% X,   B : n x r  (column-major, like w)
+ * r is the engine's rank.  Uses the factor arrays as operand storage: any VB / ML state
+ * the engine held is dropped.  Unpartitioned engines only.
+ * --------------------------------------------------------------------------------- */
+int vbnmf_engine_spmm(vbnmf_engine *e, int32_t transpose, const double *B, double *C);
+
+/* ---------------------------------------------------------------------------------
  * Host-only inspection of the tiled device layout (no GPU needed): builds the layout
  * for one side at padded rank r and hands out its arrays so tests can check, bit for
  * bit, that the slices hold exactly X.  side 0 = gene side (lanes own genes, minor =

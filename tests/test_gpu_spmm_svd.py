@@ -1,0 +1,93 @@
+"""GPU: the sparse products of the tiled layout (vbnmf_engine_spmm / k_spmm) and the truncated SVD built on them
+(ccfindr_amd/linalg.py), which stands in for irlba in the svd2 initialiser (reference R/bayesian.R:150-159).
+Checker: dense numpy products and numpy's full SVD."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+
+def counts(n, m, lam, seed):
+    rng = np.random.default_rng(seed)
+    X = rng.poisson(lam, size=(n, m)).astype(np.float64)
+    X[np.arange(n), rng.integers(0, m, n)] += 1
+    X[rng.integers(0, n, m), np.arange(m)] += 1
+    return X
+
+
+@pytest.mark.parametrize("n,m,r,lam", [(64, 96, 4, 1.5), (300, 400, 10, 0.05), (130, 70, 1, 1.0), (97, 211, 7, 0.3),
+                                       (50, 60, 20, 2.0), (40, 45, 32, 1.0), (2500, 4300, 12, 0.1)])
+def test_spmm_both_orientations(n, m, r, lam):
+    import ccfindr_amd as C
+    X = counts(n, m, lam, seed=n + r)
+    rng = np.random.default_rng(1)
+    eng = C.VBEngine(C.CountMatrix(X), r)
+    B = rng.standard_normal((r, m))
+    got = eng.spmm(B)
+    want = X @ B.T
+    assert np.max(np.abs(got - want)) <= 1e-12 * np.max(np.abs(want))
+    W = rng.standard_normal((n, r))
+    got = eng.spmm(W, transpose=True)
+    want = W.T @ X
+    assert np.max(np.abs(got - want)) <= 1e-12 * np.max(np.abs(want))
+    # the engine's state is gone after a product
+    with pytest.raises(C.VBNMFError):
+        eng.step({"aw": 1.0, "bw": 1.0, "ah": 1.0, "bh": 1.0})
+    eng.close()
+
+
+def test_spmm_wide_values_and_sparse_input():
+    import ccfindr_amd as C
+    X = counts(80, 150, 0.7, seed=5)
+    X = X * (np.median(X.sum(axis=0)) / X.sum(axis=0))[None, :]
+    X[3, 4] = 70000.25
+    rng = np.random.default_rng(2)
+    eng = C.VBEngine(C.CountMatrix(sp.csr_matrix(X)), 5)
+    B = rng.standard_normal((5, 150))
+    want = X @ B.T
+    assert np.max(np.abs(eng.spmm(B) - want)) <= 1e-12 * np.max(np.abs(want))
+    eng.close()
+
+
+def planted(n, m, k, seed):
+    """Counts with k well separated components, so the spectrum has a gap after k."""
+    rng = np.random.default_rng(seed)
+    W = rng.gamma(0.3, 1.0, size=(n, k))
+    H = np.zeros((k, m))
+    H[rng.integers(0, k, m), np.arange(m)] = rng.uniform(2, 6, m)
+    X = rng.poisson(W @ H).astype(np.float64)
+    X[np.arange(n), rng.integers(0, m, n)] += 1
+    X[rng.integers(0, n, m), np.arange(m)] += 1
+    return X
+
+
+@pytest.mark.parametrize("n,m,k", [(400, 900, 4), (1200, 700, 6)])
+def test_truncated_svd_matches_full_svd(n, m, k):
+    from ccfindr_amd.linalg import truncated_svd
+    X = planted(n, m, k, seed=n)
+    u, d, vt = truncated_svd(sp.csc_matrix(X), k)
+    U, D, Vt = np.linalg.svd(X, full_matrices=False)
+    assert np.max(np.abs(d / D[:k] - 1)) <= 1e-9
+    for i in range(k):                                    # singular vectors up to sign
+        assert abs(abs(u[:, i] @ U[:, i]) - 1) <= 1e-8 and abs(abs(vt[i] @ Vt[i]) - 1) <= 1e-8
+    assert np.allclose(u.T @ u, np.eye(k), atol=1e-12) and np.allclose(vt @ vt.T, np.eye(k), atol=1e-12)
+
+
+def test_svd2_initialiser_on_device_matches_host_svd():
+    """vb_init(initializer = 'svd2') beyond min(nrow, ncol)/2 > rank: the reference calls irlba (R/bayesian.R:154)."""
+    import ccfindr_amd as C
+    from ccfindr_amd import bayesian
+    X = planted(300, 500, 3, seed=7)
+    hy = {"aw": 1.0, "bw": 1.0, "ah": 1.0, "bh": 0.7}
+    wh = bayesian.vb_init(300, 500, sp.csc_matrix(X), 3, hy, "svd2")
+    U, D, Vt = np.linalg.svd(X, full_matrices=False)
+    w, h = np.abs(U[:, :3]), np.abs(np.diag(D[:3]) @ Vt[:3])
+    scale = hy["bh"] / np.mean(h)
+    # subspace iteration leaves the vectors at ~1e-8 absolute: entries near zero cannot be held to a relative tolerance
+    assert np.max(np.abs(wh["lw"] - w / scale)) <= 1e-6 * np.max(w / scale)
+    assert np.max(np.abs(wh["lh"] - h * scale)) <= 1e-6 * np.max(h * scale)
+    assert np.mean(wh["lh"]) == pytest.approx(hy["bh"])
+    # and through the driver: one deterministic run from that start
+    res = C.vb_factorize(sp.csc_matrix(X), ranks=3, nrun=1, initializer="svd2", verbose=0, Itmax=30)
+    assert res.basis[0].shape == (300, 3) and np.isfinite(res.measure["lml"][0])

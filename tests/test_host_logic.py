@@ -153,10 +153,13 @@ def test_uniform_basis_column_stops_the_rank_scan():
 
 def test_svd2_initialiser_shapes_and_scale():
     from ccfindr_amd import bayesian
-    X = data()
-    n, m = X.shape
+    X = data()[:6, :40]                                  # min(nrow, ncol) / 2 <= rank: the reference's full-SVD branch
+    n, m = X.shape                                       # (:151-152); the irlba branch runs on the device (GPU tests)
     wh = bayesian.vb_init(n, m, X, 3, HY1, "svd2")
     assert wh["lw"].shape == (n, 3) and wh["lh"].shape == (3, m) and (wh["lw"] >= 0).all() and (wh["lh"] >= 0).all()
+    u, d, vt = np.linalg.svd(X, full_matrices=False)
+    scale = HY1["bh"] / np.mean(np.abs(np.diag(d[:3]) @ vt[:3]))
+    assert np.allclose(wh["lw"], np.abs(u[:, :3]) / scale) and np.allclose(wh["lh"], np.abs(np.diag(d[:3]) @ vt[:3]) * scale)
     assert np.mean(wh["lh"]) == pytest.approx(HY1["bh"])                      # R/bayesian.R:157-158
     assert not wh["dw"].any() and not wh["dh"].any()
 
