@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/c5_check.py -- BASELINE.json config C5 on ONE GPU: 30 000 genes x 200 000 cells (~5 % stored), rank 20,
+"""tests/manual_c5_check.py (run by hand through gpurun; it lives under tests/ because it uses the CPU oracle as its checker) -- BASELINE.json config C5 on ONE GPU: 30 000 genes x 200 000 cells (~5 % stored), rank 20,
 cells cut 8 ways.  The eight partition engines live side by side on the one device; their reduce buffers
 [swsum | rowSums(eh) | scalars] are summed on the device where the 8-GPU run issues its RCCL all-reduce.
 
@@ -8,7 +8,7 @@ Checks   : lkh of the first steps against the stored-entries CPU restatement (or
 Measures : per-partition step_local / step_finish time (each engine timed alone), i.e. the compute part of one
            8-GPU step; the all-reduce payload.  Writes gpurun_out/c5_check.json.
 
-    python tools/c5_check.py [--cells 200000] [--parts 8] [--steps 2] [--timing-steps 20]
+    python tests/manual_c5_check.py [--cells 200000] [--parts 8] [--steps 2] [--timing-steps 20]
 """
 import argparse
 import json
@@ -18,7 +18,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))      # tests/ -> repo root
 sys.path.insert(0, ROOT)
 
 

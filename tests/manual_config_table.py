@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/config_table.py -- the BASELINE.json configurations C1..C3 side by side:
+"""tests/manual_config_table.py (run by hand through gpurun; it lives under tests/ because it uses the CPU oracle as its checker) -- the BASELINE.json configurations C1..C3 side by side:
 GPU iterations/s of the device-driven loop, the literal dense CPU restatement on ONE thread (faithful to the
 reference's src/Makevars: no OpenMP) and the stored-entries CPU restatement on the box's cores.  The dense literal
 form is timed at C1, C2 and, for C3, at the stated down-scale 20 000 x 5 000 (the first 5 000 cells) and reported per
@@ -12,7 +12,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))      # tests/ -> repo root
 sys.path.insert(0, ROOT)
 HY = {"aw": 1.0, "bw": 1.0, "ah": 1.0, "bh": 1.0}
 
