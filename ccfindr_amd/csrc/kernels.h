@@ -4,7 +4,8 @@
 // R = rank padded to even, pad columns hold 0):
 //   lw, llw, ew, dw : [n][R]       llw = lw * log(lw)
 //   lh, llh, eh, dh : [m][R]       llh = lh * log(lh)
-//   part{A,B}       : [n_blocks][n_major][R]  per-(major, minor-block) partial statistics
+//   part{A,B}       : [n_slices*64][R]  per-task partial statistics (task = one major's entries in one minor block),
+//                     summed per major in the fixed order of the layout's inverse index
 //
 // Mathematics (reference src/vbnmf_update.cpp, all citations to that file):
 //   sweep     :33-36  wth_ij = sum_k lw_ik lh_kj ; q_ij = X_ij / wth_ij ;
@@ -27,12 +28,13 @@ namespace vbnmf {
 constexpr uint32_t kIdle = 0xFFFFFFFFu;
 
 // ------------------------------------------------------------------------------------
-// Sweep.  256 persistent workgroups; each walks its cost-balanced range of slices, first of
-// the gene side then of the cell side.  Within a segment (slices of one minor block) that
-// block of the gathered factor G sits in LDS; each lane owns one task (a run of one
-// major's entries): the major's factor row F and R accumulators live in VGPRs, the entries
-// are stored lane-interleaved so a wave reads 1 KiB per load instruction, and the partial
-// statistics are written task-major (a wave writes one contiguous 64*R*8-byte piece).
+// Sweep.  One persistent workgroup per CU; each walks its cost-balanced share of the slices, first of
+// the gene side then of the cell side.  Within a segment (its slices of one minor block) that
+// block of the gathered factor G sits in LDS and the waves pull slices, longest first, through an
+// LDS ticket counter; each lane owns one task (a run of one major's entries): the major's factor
+// row F and R accumulators live in VGPRs, the entries are stored lane-interleaved so a wave reads
+// 1 KiB per load instruction, and the partial statistics are written task-major (a wave writes one
+// contiguous 64*R*8-byte piece).  No floating-point atomics anywhere: results are bit-reproducible.
 // ------------------------------------------------------------------------------------
 struct SweepSide {
     const uint32_t *packed;        // (count << 18) | (LDS slot of the minor's row << 4)   (packed layout, common.h)
