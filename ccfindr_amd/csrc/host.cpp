@@ -431,9 +431,8 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
     // persistent workgroups.  Shares are block-aligned so a workgroup stages one block per side:
     // whole workgroups are apportioned to blocks in proportion to block cost (largest remainder);
     // a block's slices, sorted by width, are dealt to its workgroups in snake order (equal cost,
-    // same mix of long and short slices); inside a share the slices are bin-packed onto the waves,
-    // longest first to the least loaded wave.  With more blocks than workgroups, whole blocks are
-    // bin-packed onto workgroups instead.
+    // same mix of long and short slices); inside a share the waves pull the slices longest first at run
+    // time (see below).  With more blocks than workgroups, whole blocks are bin-packed onto workgroups instead.
     {
         const double c0 = 10.0;                              // per-slice overhead in entry-equivalents
         auto cost = [&](int64_t s) { return (double)L.slice_width[s] + c0; };
