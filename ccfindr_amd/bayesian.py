@@ -228,10 +228,25 @@ def _bundle_rng(bundle, irun, rank):
 
 
 def _make_engine(bundle, rank):
+    """The engine of one rank.  Building one means cutting the tiled layout of X for that rank on the host (seconds
+    at C3), so the restarts of a rank (``nrun`` > 1) share it: ``bundle["engines"]`` keeps one per rank until
+    ``_close_engines``."""
+    cache = bundle.get("engines")
+    if cache is not None and rank in cache:
+        return cache[rank]
     factory = bundle.get("engine_factory")
-    if factory is not None:
-        return factory(bundle["mat"], rank)
-    return VBEngine(bundle["mat"], rank, device=bundle.get("device", 0))
+    eng = factory(bundle["mat"], rank) if factory is not None else VBEngine(bundle["mat"], rank, device=bundle.get("device", 0))
+    if cache is not None:
+        cache[rank] = eng
+    return eng
+
+
+def _close_engines(bundle):
+    cache = bundle.get("engines")
+    if cache:
+        for eng in cache.values():
+            eng.close()
+        cache.clear()
 
 
 def vb_run_rank(irun, rank, bundle):
@@ -274,7 +289,8 @@ def vb_run_rank(irun, rank, bundle):
                       f"ah = {hyper['ah']}, bh = {hyper['bh']}")
         wh = eng.get_state(("ew", "eh", "dw", "dh"))
     finally:
-        eng.close()
+        if bundle.get("engines") is None:
+            eng.close()
     if verbose >= 2:
         print(f"Rank = {rank}: Nsteps ={it}, log(evidence) ={lk0}, hyper = ({hyper['aw']},{hyper['bw']},"
               f"{hyper['ah']},{hyper['bh']})")
@@ -387,5 +403,9 @@ def vb_factorize(mat, ranks=2, nrun=1, verbose=2, progress_bar=True, initializer
     bundle = make_bundle(mat, ranks, nrun, verbose, initializer, Itmax, hyper_update, gamma_a, gamma_b, Tol,
                          hyper_update_n0, hyper_update_dn, fudge, unif_stop, seed, device, engine_factory)
     bundle["device_loop"] = bool(device_loop)      # False: step from the host (the loop below, literally)
-    vb = [vb_iterate(irun, bundle) for irun in range(1, nrun + 1)]               # :260-261
+    bundle["engines"] = {} if nrun > 1 else None   # restarts of a rank reuse its engine (its layout of X)
+    try:
+        vb = [vb_iterate(irun, bundle) for irun in range(1, nrun + 1)]           # :260-261
+    finally:
+        _close_engines(bundle)
     return select_best(vb, bundle["ranks"])

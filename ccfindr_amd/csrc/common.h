@@ -5,6 +5,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <functional>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -22,12 +24,25 @@ void parallel_for(int64_t count, const std::function<void(int64_t begin, int64_t
                   int max_threads = 0);
 int host_threads();
 
+// The same matrix by rows (genes), columns ascending in each row: what the gene side of the layout is cut from.
+struct RowMajor {
+    std::vector<int64_t> ptr;      // n+1
+    std::vector<int32_t> idx;      // nnz
+    std::vector<double> val;       // nnz
+};
+struct RowMajorCache {
+    std::once_flag once;
+    RowMajor rm;
+};
+
 // ---- canonical host copy of X: CSC, rows ascending in each column, no zeros, no dups ----
 struct Matrix {
     int64_t n = 0, m = 0, nnz = 0;
     std::vector<int64_t> colptr;   // m+1
     std::vector<int32_t> row;      // nnz
     std::vector<double> val;       // nnz
+    std::shared_ptr<RowMajorCache> rm_cache = std::make_shared<RowMajorCache>();
+    const RowMajor &row_major() const;   // lazily built, thread-safe; engines of every rank on this matrix share it
     bool counts_u16 = false;       // every stored value is an integer in [1, kPackedCountMax]: the 4-byte entry format applies
 };
 
@@ -105,6 +120,9 @@ LayoutParams default_layout_params(int64_t n_major, int64_t n_minor, int R, int 
 int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const LayoutParams &lp, Layout &out);
 
 const char *last_error_cstr();
+
+void transpose_compressed(int64_t nouter, int64_t ninner, const int64_t *ptr, const int32_t *idx, const double *val,
+                          int32_t idx_offset, std::vector<int64_t> &tptr, std::vector<int32_t> &tidx, std::vector<double> &tval);
 
 // Canonical matrix from compressed columns in any order within a column (duplicates summed, zeros dropped).
 int matrix_from_csc(int64_t n, int64_t m, const int32_t *p, const int32_t *i, const double *x, Matrix &X);

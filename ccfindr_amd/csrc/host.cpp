@@ -7,6 +7,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -81,6 +82,14 @@ static void finish_matrix(Matrix &X)
         ok = (v >= 1.0 && v <= kPackedCountMax && v == std::floor(v));
     }
     X.counts_u16 = ok;
+}
+
+const RowMajor &Matrix::row_major() const
+{
+    std::call_once(rm_cache->once, [&] {
+        transpose_compressed(m, n, colptr.data(), row.data(), val.data(), 0, rm_cache->rm.ptr, rm_cache->rm.idx, rm_cache->rm.val);
+    });
+    return rm_cache->rm;
 }
 
 static int matrix_from_dense(int64_t n, int64_t m, const double *A, Matrix &X)
@@ -176,23 +185,44 @@ int matrix_from_csc(int64_t n, int64_t m, const int32_t *p, const int32_t *i, co
     return VBNMF_OK;
 }
 
-// Transpose a canonical compressed matrix (nouter x ninner) into the other orientation.
-static void transpose_compressed(int64_t nouter, int64_t ninner, const int64_t *ptr, const int32_t *idx, const double *val,
-                                 int32_t idx_offset, std::vector<int64_t> &tptr, std::vector<int32_t> &tidx, std::vector<double> &tval)
+// Transpose a canonical compressed matrix (nouter x ninner) into the other orientation (inner indices of the
+// result ascending).  Outer vectors are cut into one chunk per thread; each chunk counts its entries per inner
+// index, an exclusive scan over (inner index, chunk) gives every chunk its write positions, then the chunks scatter.
+void transpose_compressed(int64_t nouter, int64_t ninner, const int64_t *ptr, const int32_t *idx, const double *val,
+                          int32_t idx_offset, std::vector<int64_t> &tptr, std::vector<int32_t> &tidx, std::vector<double> &tval)
 {
+    const int64_t s = ptr[0], t = ptr[nouter];
+    int T = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), (t - s) / (1 << 18) + 1));
+    while (T > 1 && (int64_t)T * ninner > (int64_t)1 << 28) T /= 2;             // cap the counter table at 2 GiB
+    std::vector<int64_t> cut(T + 1);
+    for (int c = 0; c <= T; c++) cut[c] = nouter * c / T;
+    std::vector<int64_t> cnt((size_t)T * ninner, 0);
+    parallel_for(T, [&](int64_t b, int64_t e, int) {
+        for (int64_t c = b; c < e; c++) {
+            int64_t *my = &cnt[(size_t)c * ninner];
+            for (int64_t q = ptr[cut[c]]; q < ptr[cut[c + 1]]; q++) my[idx[q]]++;
+        }
+    }, T);
     tptr.assign(ninner + 1, 0);
-    int64_t s = ptr[0], t = ptr[nouter];
-    for (int64_t e = s; e < t; e++) tptr[idx[e] + 1]++;
-    for (int64_t i = 0; i < ninner; i++) tptr[i + 1] += tptr[i];
+    int64_t run = 0;
+    for (int64_t i = 0; i < ninner; i++) {
+        tptr[i] = run;
+        for (int c = 0; c < T; c++) { const int64_t k = cnt[(size_t)c * ninner + i]; cnt[(size_t)c * ninner + i] = run; run += k; }
+    }
+    tptr[ninner] = run;
     tidx.resize(t - s);
     tval.resize(t - s);
-    std::vector<int64_t> cur(tptr.begin(), tptr.end() - 1);
-    for (int64_t j = 0; j < nouter; j++)
-        for (int64_t e = ptr[j]; e < ptr[j + 1]; e++) {
-            int64_t o = cur[idx[e]]++;
-            tidx[o] = (int32_t)(j - idx_offset);
-            tval[o] = val[e];
+    parallel_for(T, [&](int64_t b, int64_t e, int) {
+        for (int64_t c = b; c < e; c++) {
+            int64_t *cur = &cnt[(size_t)c * ninner];
+            for (int64_t j = cut[c]; j < cut[c + 1]; j++)
+                for (int64_t q = ptr[j]; q < ptr[j + 1]; q++) {
+                    const int64_t o = cur[idx[q]]++;
+                    tidx[o] = (int32_t)(j - idx_offset);
+                    tval[o] = val[q];
+                }
         }
+    }, T);
 }
 
 static int matrix_from_csr(int64_t n, int64_t m, const int32_t *p, const int32_t *j, const double *x, Matrix &X)
@@ -304,6 +334,8 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
         (int64_t)lp.block_width * lp.row_slots > (int64_t)(kPackedOffsetMask >> 4) + 1)
         return fail(VBNMF_ERR_BAD_ARG, "bad layout parameters");
 
+    auto T0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) { if (getenv("VBNMF_BUILD_TIMES")) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "  layout side %d %-12s %.3f s\n", side, what, std::chrono::duration<double>(t - T0).count()); T0 = t; } };
     // major-compressed view of X[:, cb:ce)
     std::vector<int64_t> tptr;
     std::vector<int32_t> tidx;
@@ -316,9 +348,15 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
         ptr = X.colptr.data() + cb; idx = X.row.data(); val = X.val.data();
     } else {
         L.n_major = X.n; L.n_minor = ce - cb;
-        transpose_compressed(ce - cb, X.n, X.colptr.data() + cb, X.row.data(), X.val.data(), 0, tptr, tidx, tval);
-        ptr = tptr.data(); idx = tidx.data(); val = tval.data();
+        if (cb == 0 && ce == X.m) {
+            const RowMajor &Rm = X.row_major();               // built once per matrix, shared by every engine on it
+            ptr = Rm.ptr.data(); idx = Rm.idx.data(); val = Rm.val.data();
+        } else {
+            transpose_compressed(ce - cb, X.n, X.colptr.data() + cb, X.row.data(), X.val.data(), 0, tptr, tidx, tval);
+            ptr = tptr.data(); idx = tidx.data(); val = tval.data();
+        }
     }
+    lap("transpose");
     L.side = side;
     L.wide = !X.counts_u16;
     L.block_width = lp.block_width;
@@ -345,6 +383,7 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
         }
     });
 
+    lap("bpos");
     // tasks per block: (major, block) runs longer than max_len are cut in near-equal pieces
     struct Task { uint32_t major; int32_t len; int64_t pos; };
     std::vector<std::vector<Task>> btasks(nblk);
@@ -365,6 +404,7 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
         }
     });
 
+    lap("tasks");
     // slices: 64 consecutive tasks of a block; blocks in index order
     std::vector<int64_t> bslice0(nblk + 1, 0);
     for (int32_t blk = 0; blk < nblk; blk++)
@@ -428,6 +468,7 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
     }
     };
 
+    lap("slices");
     // persistent workgroups.  Shares are block-aligned so a workgroup stages one block per side:
     // whole workgroups are apportioned to blocks in proportion to block cost (largest remainder);
     // a block's slices, sorted by width, are dealt to its workgroups in snake order (equal cost,
@@ -537,7 +578,9 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
         int64_t o2 = 0;
         for (int64_t s = 0; s < L.n_slices; s++) { L.slice_off[s] = o2; o2 += (int64_t)L.slice_width[s] * kLanes; }
     }
+    lap("shares");
     build_inverse();
+    lap("inverse");
 
     try {
         if (L.wide) { L.wide_idx.assign(L.n_slots, 0u); L.wide_val.assign(L.n_slots, 0.0); }
@@ -557,6 +600,7 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
     // distinct residues (local mod 16) to its lanes: residues in order of remaining demand, each to
     // the lane with the fewest other residues left; a lane that finds all its residues taken
     // doubles up on the least used one.
+    lap("alloc");
     static const int kGroupOf[64] = {0,0,0,0,1,1,1,1,1,1,1,1,0,0,0,0,1,1,1,1,0,0,0,0,0,0,0,0,1,1,1,1,
                                      2,2,2,2,3,3,3,3,3,3,3,3,2,2,2,2,3,3,3,3,2,2,2,2,2,2,2,2,3,3,3,3};
     const bool schedule = env_int("VBNMF_NO_BANK_SCHEDULE", 0) == 0;
@@ -583,7 +627,7 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
             for (int g = 0; g < 4; g++) {
                 int lanes[16], nl = 0;
                 for (int lane = 0; lane < kLanes; lane++) if (kGroupOf[lane] == g) lanes[nl++] = lane;
-                int cnt[16][16] = {}, rem[16] = {}, step[16] = {}, dem[16] = {};
+                int cnt[16][16] = {}, rem[16] = {}, step[16] = {}, dem[16] = {}, nopt[16] = {};
                 int T = 0;
                 for (int j = 0; j < 16; j++) {
                     for (int r = 0; r < 16; r++) bucket[j][r].clear();
@@ -593,7 +637,8 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
                     for (int32_t t = task_len[id] - 1; t >= 0; t--) {      // reversed: stacks pop in ascending minor order
                         int r = (idx[q0 + t] - m0) & 15;
                         bucket[j][r].push_back(t);
-                        cnt[j][r]++; dem[r]++;
+                        if (cnt[j][r]++ == 0) nopt[j]++;      // nopt[j]: residues lane j still has entries of
+                        dem[r]++;
                     }
                     rem[j] = task_len[id];
                     T = std::max(T, rem[j]);
@@ -609,7 +654,8 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
                         int32_t tt = bucket[j][r].back();
                         bucket[j][r].pop_back();
                         put(lanes[j], step[j]++, task_pos[id] + tt);
-                        assigned[j] = true; used[r]++; cnt[j][r]--; dem[r]--; rem[j]--;
+                        assigned[j] = true; used[r]++; dem[r]--; rem[j]--;
+                        if (--cnt[j][r] == 0) nopt[j]--;
                     };
                     for (int oi = 0; oi < 16; oi++) {
                         const int r = ord[oi];
@@ -617,9 +663,7 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
                         int best = -1, best_opt = 99, best_cnt = -1;
                         for (int j = 0; j < 16; j++) {
                             if (assigned[j] || rem[j] == 0 || cnt[j][r] == 0) continue;
-                            int nopt = 0;
-                            for (int r2 = 0; r2 < 16; r2++) nopt += cnt[j][r2] > 0;
-                            if (nopt < best_opt || (nopt == best_opt && cnt[j][r] > best_cnt)) { best = j; best_opt = nopt; best_cnt = cnt[j][r]; }
+                            if (nopt[j] < best_opt || (nopt[j] == best_opt && cnt[j][r] > best_cnt)) { best = j; best_opt = nopt[j]; best_cnt = cnt[j][r]; }
                         }
                         if (best >= 0) take(best, r);
                     }
@@ -636,6 +680,7 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
             }
         }
     });
+    lap("fill");
     return VBNMF_OK;
 }
 

@@ -19,7 +19,7 @@ import math
 
 import numpy as np
 
-from .bayesian import assemble_run, make_bundle, select_best, vb_run_rank
+from .bayesian import _close_engines, assemble_run, make_bundle, select_best, vb_run_rank
 from .engine import EPS, VBEngine
 
 
@@ -68,7 +68,11 @@ def vb_factorize_sharded(mat, ranks=2, nrun=1, verbose=0, initializer="random", 
                          hyper_update_n0, hyper_update_dn, fudge, unif_stop, seed, device, engine_factory)
     tasks, costs = sweep_tasks(bundle["ranks"], nrun)
     mine = lpt_schedule(costs, world)[me]
-    local = {tasks[t]: vb_run_rank(tasks[t][0], tasks[t][1], bundle) for t in mine}
+    bundle["engines"] = {} if nrun > 1 else None        # this process's restarts of a rank share the engine
+    try:
+        local = {tasks[t]: vb_run_rank(tasks[t][0], tasks[t][1], bundle) for t in mine}
+    finally:
+        _close_engines(bundle)
     if world > 1:
         gathered = [None] * world
         dist.all_gather_object(gathered, local, group=group)        # control plane: host objects, once per sweep
