@@ -7,7 +7,10 @@
 #include "common.h"
 
 #include <algorithm>
+#include <sched.h>
+
 #include <chrono>
+#include <system_error>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -52,6 +55,8 @@ int host_threads()
         }
         unsigned hc = std::thread::hardware_concurrency();
         int v = hc ? (int)hc : 1;
+        cpu_set_t set;                                   // a rank pinned to a subset of the cores uses only those
+        if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0) v = std::min(v, CPU_COUNT(&set));
         return std::min(v, 32);
     }();
     return n;
@@ -67,7 +72,11 @@ void parallel_for(int64_t count, const std::function<void(int64_t, int64_t, int)
     th.reserve(nt);
     for (int t = 0; t < nt; t++) {
         int64_t b = count * t / nt, e = count * (t + 1) / nt;
-        th.emplace_back([&fn, b, e, t] { fn(b, e, t); });
+        try {
+            th.emplace_back([&fn, b, e, t] { fn(b, e, t); });
+        } catch (const std::system_error &) {            // thread limit reached: this piece runs here
+            fn(b, e, t);
+        }
     }
     for (auto &x : th) x.join();
 }
