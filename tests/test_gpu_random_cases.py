@@ -1,0 +1,67 @@
+"""GPU parity on randomly drawn shapes, ranks, densities, value kinds and hyper-parameters (seeded): VB step and
+ML step through the stateless C ABI against the dense literal oracles.  Covers the corners the hand-picked cases
+may miss: single rows / columns, all-zero rows and columns inside X, rank above min(n, m), dense and nearly empty
+matrices, non-integer and > 16383 values (wide layout), tiny and large hyper-parameters."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def relerr(a, b):
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300)))
+
+
+def draw(seed):
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.choice([1, 2, 7, 33, 64, 65, 130, 257, 400]))
+    m = int(rng.choice([1, 3, 16, 63, 64, 129, 300, 600, 2100]))
+    r = int(rng.integers(1, 33))
+    lam = float(rng.choice([0.01, 0.05, 0.3, 1.0, 4.0]))
+    X = rng.poisson(lam, size=(n, m)).astype(np.float64)
+    kind = int(rng.integers(0, 4))
+    if kind == 1:                                      # non-integer values
+        X = X * rng.uniform(0.5, 1.5, size=(1, m))
+    elif kind == 2 and X.size:                         # a value beyond the packed range
+        X[rng.integers(0, n), rng.integers(0, m)] = 20000.0 + rng.integers(0, 100000)
+    if n > 3 and rng.random() < 0.5:
+        X[rng.integers(0, n), :] = 0.0                 # an all-zero gene
+    if m > 3 and rng.random() < 0.5:
+        X[:, rng.integers(0, m)] = 0.0                 # an all-zero cell
+    if not X.any():
+        X[0, 0] = 1.0
+    hy = {k: float(rng.choice([0.05, 0.5, 1.0, 3.0, 40.0])) for k in ("aw", "bw", "ah", "bh")}
+    return np.asfortranarray(X), r, hy, rng
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_vb_step_random_case(seed):
+    import ccfindr_amd as C
+    from ccfindr_amd import synth
+    from oracle import vbnmf_oracle as O
+    X, r, hy, rng = draw(seed)
+    n, m = X.shape
+    wh = synth.random_state(n, m, r, hy, seed=seed)
+    got = C.vbnmf_update(X, wh, hy, C.EPS)
+    want = O.update_dense(X, wh, hy, C.EPS)
+    for k in ("lw", "lh", "ew", "eh", "dw", "dh"):
+        assert relerr(got[k], want[k]) <= 1e-12, (seed, k, relerr(got[k], want[k]))
+    assert abs(got["lkh"] / want["lkh"] - 1) <= 1e-10, (seed, got["lkh"], want["lkh"])
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_ml_step_random_case(seed):
+    import ccfindr_amd as C
+    from oracle import mlnmf_oracle as O
+    X, r, _, rng = draw(seed)
+    n, m = X.shape
+    w, h = rng.uniform(0.05, 1.0, size=(n, r)), rng.uniform(0.05, 1.0, size=(r, m))
+    got = C.nmf_update(X, w, h)
+    want = O.nmf_update_literal(X, w, h)
+    assert relerr(got["ew"], want["ew"]) <= 1e-12 and relerr(got["eh"], want["eh"]) <= 1e-12, seed
+    lk = O.likelihood_literal(X, want["ew"], want["eh"])
+    # the likelihood is a difference of large sums (it is exactly 0 when w h reproduces x): hold the error to the
+    # size of those sums, not to the size of the result
+    wh = want["ew"] @ want["eh"]
+    scale = (np.abs(X * np.log(wh)).sum() + wh.sum()) / n / m
+    assert abs(got["lk"] - lk) <= 1e-11 * scale, (seed, got["lk"], lk, scale)
