@@ -130,10 +130,28 @@ int matrix_from_csc(int64_t n, int64_t m, const int32_t *p, const int32_t *i, co
 }  // namespace vbnmf
 
 // opaque handles of the C ABI
+// Whole-matrix layouts already cut for this matrix, by geometry.  The tiled layout depends on the rank only through
+// the LDS row size (the same for padded ranks 8 and 10, 12 and 14, ...), so the engines of a rank sweep and the
+// restarts of a rank share a few of them instead of rebuilding one each (seconds of host time at C3).
+struct LayoutCache {
+    struct Entry {
+        int side;
+        vbnmf::LayoutParams lp;
+        std::shared_ptr<const vbnmf::Layout> layout;
+    };
+    std::mutex mu;
+    std::vector<Entry> entries;    // most recent last; capped (VBNMF_LAYOUT_CACHE pairs, default 3, 0 = off)
+};
 struct vbnmf_matrix {
     vbnmf::Matrix M;
     double lgx = 0.0;      // sum over stored entries of lgamma(x+1)
+    mutable LayoutCache layouts;
 };
+namespace vbnmf {
+// The layout of `side` for the whole matrix at the default geometry of padded rank R: from the matrix's cache, or
+// built now (and cached).  rc != 0 and a null pointer on failure.
+std::shared_ptr<const Layout> shared_layout(const vbnmf_matrix *X, int side, const LayoutParams &lp, int &rc);
+}
 struct vbnmf_layout {
     vbnmf::Layout L;
 };

@@ -501,12 +501,19 @@ int vbnmf_engine_create_part(const vbnmf_matrix *X, int64_t cb, int64_t ce, int6
 
     try {
         for (int side = 0; side < 2 && !rc; side++) {
-            Layout L;
             int64_t nmaj = side == 0 ? e->n : e->m, nmin = side == 0 ? e->m : e->n;
             LayoutParams lp = default_layout_params(nmaj, nmin, e->R, e->n_wg);
-            rc = build_layout(X->M, cb, ce, side, lp, L);
-            if (!rc) rc = upload_side(L, e->R, side == 0 ? e->A : e->B);
-            if (side == 0) e->nnz = L.nnz;
+            std::shared_ptr<const Layout> shared;
+            Layout own;
+            const Layout *L = &own;
+            if (cb == 0 && ce == X->M.m) {                   // whole matrix: the layout may already exist (another rank, a restart)
+                shared = shared_layout(X, side, lp, rc);
+                L = shared.get();
+            } else {
+                rc = build_layout(X->M, cb, ce, side, lp, own);
+            }
+            if (!rc) rc = upload_side(*L, e->R, side == 0 ? e->A : e->B);
+            if (!rc && side == 0) e->nnz = L->nnz;
         }
     } catch (const std::bad_alloc &) {
         rc = fail(VBNMF_ERR_OOM, "out of host memory building the tiled layout");

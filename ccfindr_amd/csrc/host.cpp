@@ -693,6 +693,36 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
     return VBNMF_OK;
 }
 
+std::shared_ptr<const Layout> shared_layout(const vbnmf_matrix *X, int side, const LayoutParams &lp, int &rc)
+{
+    rc = VBNMF_OK;
+    const int cap = 2 * std::max(0, env_int("VBNMF_LAYOUT_CACHE", 3));       // entries = pairs x 2 sides
+    LayoutCache &C = X->layouts;
+    auto same = [&](const LayoutCache::Entry &q) {
+        return q.side == side && q.lp.block_width == lp.block_width && q.lp.max_len == lp.max_len && q.lp.n_wg == lp.n_wg &&
+               q.lp.row_slots == lp.row_slots;
+    };
+    {
+        std::lock_guard<std::mutex> g(C.mu);
+        for (size_t i = 0; i < C.entries.size(); i++)
+            if (same(C.entries[i])) {
+                LayoutCache::Entry hit = C.entries[i];
+                C.entries.erase(C.entries.begin() + i);
+                C.entries.push_back(hit);                                  // most recently used last
+                return hit.layout;
+            }
+    }
+    auto L = std::make_shared<Layout>();
+    rc = build_layout(X->M, 0, X->M.m, side, lp, *L);
+    if (rc) return nullptr;
+    if (cap > 0) {
+        std::lock_guard<std::mutex> g(C.mu);
+        C.entries.push_back({side, lp, L});
+        while ((int)C.entries.size() > cap) C.entries.erase(C.entries.begin());
+    }
+    return L;
+}
+
 }  // namespace vbnmf
 
 // ====================================================================== C ABI (host-only part)
