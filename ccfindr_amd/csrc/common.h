@@ -139,8 +139,16 @@ struct LayoutCache {
         vbnmf::LayoutParams lp;
         std::shared_ptr<const vbnmf::Layout> layout;
     };
+    // The device-resident copy of a cached layout's arrays on one device, shared by every engine created from it
+    // there (engine.hip owns the type behind `arrays`; it is freed when the last engine and the cache let go).
+    struct DeviceCopy {
+        const vbnmf::Layout *key;
+        int device;
+        std::shared_ptr<void> arrays;
+    };
     std::mutex mu;
     std::vector<Entry> entries;    // most recent last; capped (VBNMF_LAYOUT_CACHE pairs, default 3, 0 = off)
+    std::vector<DeviceCopy> copies;  // only of layouts still in `entries`
 };
 struct vbnmf_matrix {
     vbnmf::Matrix M;
@@ -151,6 +159,9 @@ namespace vbnmf {
 // The layout of `side` for the whole matrix at the default geometry of padded rank R: from the matrix's cache, or
 // built now (and cached).  rc != 0 and a null pointer on failure.
 std::shared_ptr<const Layout> shared_layout(const vbnmf_matrix *X, int side, const LayoutParams &lp, int &rc);
+// Device copies of cached layouts: look one up (null if absent) / remember one (ignored if the layout is not cached).
+std::shared_ptr<void> cached_device_copy(const vbnmf_matrix *X, const Layout *L, int device);
+void store_device_copy(const vbnmf_matrix *X, const Layout *L, int device, std::shared_ptr<void> arrays);
 }
 struct vbnmf_layout {
     vbnmf::Layout L;

@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <new>
 
 #include "common.h"
@@ -35,12 +36,33 @@ using namespace vbnmf;
 
 namespace {
 
-struct DeviceSide {
+// The layout's arrays on the device.  Engines made from a cached layout (same matrix, same geometry, same device)
+// share one of these; the per-engine part is DeviceSide::part.
+struct DeviceArrays {
+    int device = 0;
     uint32_t *packed = nullptr, *widx = nullptr, *task_major = nullptr, *inv_task = nullptr;
     double *wval = nullptr;
     int32_t *slice_width = nullptr, *seg_block = nullptr, *seg_ptr = nullptr, *wg_seg0 = nullptr, *inv_ptr = nullptr;
     int64_t *slice_off = nullptr;
-    double *part = nullptr;
+    ~DeviceArrays()
+    {
+        int cur = -1;
+        (void)hipGetDevice(&cur);
+        (void)hipSetDevice(device);
+        (void)hipFree(packed); (void)hipFree(widx); (void)hipFree(wval); (void)hipFree(task_major); (void)hipFree(inv_task);
+        (void)hipFree(slice_width); (void)hipFree(seg_block); (void)hipFree(seg_ptr); (void)hipFree(wg_seg0); (void)hipFree(inv_ptr);
+        (void)hipFree(slice_off);
+        if (cur >= 0) (void)hipSetDevice(cur);
+    }
+};
+
+struct DeviceSide {
+    std::shared_ptr<DeviceArrays> arrays;      // owner of the pointers below (possibly shared with other engines)
+    uint32_t *packed = nullptr, *widx = nullptr, *task_major = nullptr, *inv_task = nullptr;
+    double *wval = nullptr;
+    int32_t *slice_width = nullptr, *seg_block = nullptr, *seg_ptr = nullptr, *wg_seg0 = nullptr, *inv_ptr = nullptr;
+    int64_t *slice_off = nullptr;
+    double *part = nullptr;                    // this engine's per-task partial statistics
     int64_t n_major = 0, n_minor = 0, n_tasks = 0, n_slices = 0, n_slots = 0;
     int32_t block_width = 0, n_blocks = 0, n_wg = 0;
     bool wide = false;
@@ -106,30 +128,40 @@ namespace {
 
 void free_side(DeviceSide &S)
 {
-    (void)hipFree(S.packed); (void)hipFree(S.widx); (void)hipFree(S.wval); (void)hipFree(S.task_major);
-    (void)hipFree(S.inv_task); (void)hipFree(S.slice_width); (void)hipFree(S.seg_block); (void)hipFree(S.seg_ptr);
-    (void)hipFree(S.wg_seg0); (void)hipFree(S.inv_ptr); (void)hipFree(S.slice_off); (void)hipFree(S.part);
-    S = DeviceSide();
+    (void)hipFree(S.part);
+    S = DeviceSide();                          // drops this engine's reference to the (shared) layout arrays
 }
 
-int upload_side(const Layout &L, int R, DeviceSide &S)
+// Device copy of a layout's arrays; `X` != null: the layout is (possibly) cached on the matrix and so is its copy.
+int upload_side(const Layout &L, int R, int device, const vbnmf_matrix *X, DeviceSide &S)
 {
     S.n_major = L.n_major; S.n_minor = L.n_minor; S.n_tasks = L.n_tasks; S.n_slices = L.n_slices;
     S.n_slots = L.n_slots; S.block_width = L.block_width; S.n_blocks = L.n_blocks; S.n_wg = L.n_wg; S.wide = L.wide;
-    if (L.wide) {
-        if (int rc = dev_upload(&S.widx, L.wide_idx)) return rc;
-        if (int rc = dev_upload(&S.wval, L.wide_val)) return rc;
-    } else {
-        if (int rc = dev_upload(&S.packed, L.packed)) return rc;
+    std::shared_ptr<DeviceArrays> A;
+    if (X) A = std::static_pointer_cast<DeviceArrays>(cached_device_copy(X, &L, device));
+    if (!A) {
+        A = std::make_shared<DeviceArrays>();
+        A->device = device;
+        if (L.wide) {
+            if (int rc = dev_upload(&A->widx, L.wide_idx)) return rc;
+            if (int rc = dev_upload(&A->wval, L.wide_val)) return rc;
+        } else {
+            if (int rc = dev_upload(&A->packed, L.packed)) return rc;
+        }
+        if (int rc = dev_upload(&A->task_major, L.task_major)) return rc;
+        if (int rc = dev_upload(&A->slice_width, L.slice_width)) return rc;
+        if (int rc = dev_upload(&A->slice_off, L.slice_off)) return rc;
+        if (int rc = dev_upload(&A->seg_block, L.seg_block)) return rc;
+        if (int rc = dev_upload(&A->seg_ptr, L.seg_ptr)) return rc;
+        if (int rc = dev_upload(&A->wg_seg0, L.wg_seg0)) return rc;
+        if (int rc = dev_upload(&A->inv_ptr, L.inv_ptr)) return rc;
+        if (int rc = dev_upload(&A->inv_task, L.inv_task)) return rc;
+        if (X) store_device_copy(X, &L, device, A);
     }
-    if (int rc = dev_upload(&S.task_major, L.task_major)) return rc;
-    if (int rc = dev_upload(&S.slice_width, L.slice_width)) return rc;
-    if (int rc = dev_upload(&S.slice_off, L.slice_off)) return rc;
-    if (int rc = dev_upload(&S.seg_block, L.seg_block)) return rc;
-    if (int rc = dev_upload(&S.seg_ptr, L.seg_ptr)) return rc;
-    if (int rc = dev_upload(&S.wg_seg0, L.wg_seg0)) return rc;
-    if (int rc = dev_upload(&S.inv_ptr, L.inv_ptr)) return rc;
-    if (int rc = dev_upload(&S.inv_task, L.inv_task)) return rc;
+    S.arrays = A;
+    S.packed = A->packed; S.widx = A->widx; S.wval = A->wval; S.task_major = A->task_major; S.inv_task = A->inv_task;
+    S.slice_width = A->slice_width; S.seg_block = A->seg_block; S.seg_ptr = A->seg_ptr; S.wg_seg0 = A->wg_seg0;
+    S.inv_ptr = A->inv_ptr; S.slice_off = A->slice_off;
     if (int rc = dev_alloc(&S.part, (size_t)L.n_slices * kLanes * R)) return rc;
     return VBNMF_OK;
 }
@@ -512,7 +544,7 @@ int vbnmf_engine_create_part(const vbnmf_matrix *X, int64_t cb, int64_t ce, int6
             } else {
                 rc = build_layout(X->M, cb, ce, side, lp, own);
             }
-            if (!rc) rc = upload_side(*L, e->R, side == 0 ? e->A : e->B);
+            if (!rc) rc = upload_side(*L, e->R, device, shared ? X : nullptr, side == 0 ? e->A : e->B);
             if (!rc && side == 0) e->nnz = L->nnz;
         }
     } catch (const std::bad_alloc &) {

@@ -718,9 +718,35 @@ std::shared_ptr<const Layout> shared_layout(const vbnmf_matrix *X, int side, con
     if (cap > 0) {
         std::lock_guard<std::mutex> g(C.mu);
         C.entries.push_back({side, lp, L});
-        while ((int)C.entries.size() > cap) C.entries.erase(C.entries.begin());
+        while ((int)C.entries.size() > cap) {
+            const Layout *gone = C.entries.front().layout.get();
+            C.entries.erase(C.entries.begin());
+            for (size_t i = 0; i < C.copies.size();)          // its device copies live on only in the engines that use them
+                if (C.copies[i].key == gone) C.copies.erase(C.copies.begin() + i); else i++;
+        }
     }
     return L;
+}
+
+std::shared_ptr<void> cached_device_copy(const vbnmf_matrix *X, const Layout *L, int device)
+{
+    LayoutCache &C = X->layouts;
+    std::lock_guard<std::mutex> g(C.mu);
+    for (const auto &c : C.copies)
+        if (c.key == L && c.device == device) return c.arrays;
+    return nullptr;
+}
+
+void store_device_copy(const vbnmf_matrix *X, const Layout *L, int device, std::shared_ptr<void> arrays)
+{
+    LayoutCache &C = X->layouts;
+    std::lock_guard<std::mutex> g(C.mu);
+    bool cached = false;
+    for (const auto &q : C.entries) cached |= q.layout.get() == L;
+    if (!cached) return;
+    for (const auto &c : C.copies)
+        if (c.key == L && c.device == device) return;         // another thread was first
+    C.copies.push_back({L, device, std::move(arrays)});
 }
 
 }  // namespace vbnmf
