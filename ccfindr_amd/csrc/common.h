@@ -43,7 +43,11 @@ struct Matrix {
     std::vector<double> val;       // nnz
     std::shared_ptr<RowMajorCache> rm_cache = std::make_shared<RowMajorCache>();
     const RowMajor &row_major() const;   // lazily built, thread-safe; engines of every rank on this matrix share it
-    bool counts_u16 = false;       // every stored value is an integer in [1, kPackedCountMax]: the 4-byte entry format applies
+    bool counts_u16 = false;       // every stored value is an integer in [1, kPackedCountMax]
+    bool counts_int = false;       // every stored value is an integer in [1, 2^31): the 4-byte entry format applies
+                                   // (a count above kPackedCountMax is stored as several entries of the same minor --
+                                   // every use of an entry in the sweeps is linear in its value)
+    double max_val = 0.0;
 };
 
 // sum over stored entries of lgamma(x+1) for columns [cb, ce), fixed summation order.

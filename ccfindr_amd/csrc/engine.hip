@@ -524,7 +524,7 @@ int vbnmf_engine_create_part(const vbnmf_matrix *X, int64_t cb, int64_t ce, int6
     e->n = X->M.n; e->m = ce - cb; e->m_global = m_global;
     e->r = r; e->R = padded_rank(r);
     e->NT = sweep_threads(e->R);
-    e->wide = !X->M.counts_u16;
+    e->wide = !X->M.counts_int;
     e->n_wg = n_cu;                      // one persistent workgroup per CU
     if (const char *sv = getenv("VBNMF_NWG")) { int v = atoi(sv); if (v > 0) e->n_wg = v; }
     e->partitioned = (ce - cb) != m_global;

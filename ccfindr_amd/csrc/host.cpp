@@ -85,12 +85,16 @@ void parallel_for(int64_t count, const std::function<void(int64_t, int64_t, int)
 static void finish_matrix(Matrix &X)
 {
     X.nnz = X.colptr[X.m];
-    bool ok = true;
-    for (int64_t e = 0; e < X.nnz && ok; e++) {
-        double v = X.val[e];
-        ok = (v >= 1.0 && v <= kPackedCountMax && v == std::floor(v));
+    bool ints = true;
+    double mx = 0.0;
+    for (int64_t e = 0; e < X.nnz; e++) {
+        const double v = X.val[e];
+        ints = ints && v >= 1.0 && v < 2147483648.0 && v == std::floor(v);
+        mx = std::max(mx, v);
     }
-    X.counts_u16 = ok;
+    X.counts_int = ints;
+    X.max_val = mx;
+    X.counts_u16 = ints && mx <= kPackedCountMax;
 }
 
 const RowMajor &Matrix::row_major() const
@@ -367,7 +371,36 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
     }
     lap("transpose");
     L.side = side;
-    L.wide = !X.counts_u16;
+    L.wide = !X.counts_int;
+    L.nnz = ptr[L.n_major] - ptr[0];                     // stored entries of X (before any splitting below)
+    // integer counts above the packed range: the entry is stored as ceil(x / kPackedCountMax) entries of the same minor
+    std::vector<int64_t> xptr;
+    std::vector<int32_t> xidx;
+    std::vector<double> xval;
+    if (!L.wide && X.max_val > kPackedCountMax) {
+        const int64_t nm = L.n_major;
+        xptr.assign(nm + 1, 0);
+        for (int64_t M = 0; M < nm; M++) {
+            int64_t c = 0;
+            for (int64_t q = ptr[M]; q < ptr[M + 1]; q++) c += (int64_t)std::ceil(val[q] / kPackedCountMax);
+            xptr[M + 1] = xptr[M] + c;
+        }
+        xidx.resize(xptr[nm]); xval.resize(xptr[nm]);
+        parallel_for(nm, [&](int64_t b, int64_t e, int) {
+            for (int64_t M = b; M < e; M++) {
+                int64_t o = xptr[M];
+                for (int64_t q = ptr[M]; q < ptr[M + 1]; q++) {
+                    double left = val[q];
+                    while (left > 0.0) {
+                        const double piece = std::min(left, kPackedCountMax);
+                        xidx[o] = idx[q]; xval[o] = piece; o++;
+                        left -= piece;
+                    }
+                }
+            }
+        });
+        ptr = xptr.data(); idx = xidx.data(); val = xval.data();
+    }
     L.block_width = lp.block_width;
     L.max_len = lp.max_len;
     L.n_wg = lp.n_wg;
@@ -376,7 +409,6 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
     const int32_t C = L.block_width;
     const int32_t nblk = (int32_t)((L.n_minor + C - 1) / C);
     L.n_blocks = nblk;
-    L.nnz = ptr[nmaj] - ptr[0];
 
     // bpos[major][b] = position of the major's first entry whose minor is in block >= b
     std::vector<int64_t> bpos((size_t)nmaj * (nblk + 1));

@@ -254,7 +254,8 @@ int vbnmf_engine_spmm(vbnmf_engine *e, int32_t transpose, const double *B, doubl
  * --------------------------------------------------------------------------------- */
 typedef struct vbnmf_layout vbnmf_layout;
 typedef struct {
-    int32_t side, wide;            /* wide: 0 = 4-byte entries (integer counts <= 16383), 1 = u32 index + f64 value */
+    int32_t side, wide;            /* wide: 0 = 4-byte entries (integer counts; one above 16383 takes several slots of the
+                                      same minor), 1 = u32 index + f64 value (non-integer X) */
     int64_t n_major, n_minor;      /* lanes own majors; minors are gathered from LDS */
     int32_t block_width;           /* minors per LDS block */
     int32_t n_blocks;              /* ceil(n_minor / block_width) */

@@ -72,7 +72,7 @@ def test_non_integer_counts_use_wide_layout():
     check_step(C.vbnmf_update(X, wh, HY1, C.EPS), O.update_dense(X, wh, HY1, C.EPS))
 
 
-def test_large_counts_above_u16_use_wide_layout():
+def test_large_counts_above_the_packed_range_are_split():
     import ccfindr_amd as C
     from ccfindr_amd import synth
     from oracle import vbnmf_oracle as O

@@ -104,3 +104,21 @@ def test_bad_indices_are_rejected():
         C.CountMatrix.from_csc(3, 1, p, np.array([3], dtype=np.int32), np.array([1.0]))
     with pytest.raises(C.VBNMFError):
         C.CountMatrix.from_csc(3, 1, np.array([0, 2], dtype=np.int32), np.array([0, -1], dtype=np.int32), np.array([1.0, 1.0]))
+
+
+def test_counts_above_the_packed_range_are_split_not_widened():
+    """Integer counts beyond 16383 keep the 4-byte entry format: the entry becomes several slots of the same minor."""
+    import ccfindr_amd as C
+    rng = np.random.default_rng(11)
+    X = rng.poisson(0.6, size=(90, 140)).astype(np.float64)
+    X[np.arange(90), rng.integers(0, 140, 90)] += 1
+    X[rng.integers(0, 90, 140), np.arange(140)] += 1
+    X[5, 7] = 16383.0; X[6, 8] = 16384.0; X[7, 9] = 70000.0; X[8, 10] = 3 * 16383.0
+    M = C.CountMatrix(X)
+    for side in (0, 1):
+        v = build_layout(M, side, 6)
+        assert not v["wide"]
+        A = reconstruct(v)
+        assert np.array_equal(A, X if side == 0 else X.T)
+    Y = X.copy(); Y[1, 1] = 2.5                       # one non-integer value: the wide layout
+    assert build_layout(C.CountMatrix(Y), 0, 6)["wide"]
