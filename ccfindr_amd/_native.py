@@ -94,6 +94,7 @@ SIGNATURES = {
                                              c_double_p, c_double_p, c_double_p]),
     "vbnmf_ml_update_csc": (ctypes.c_int, [_I64, _I64, _I32, c_int32_p, c_int32_p, c_double_p, c_double_p, c_double_p,
                                            _I32, _D, _D, c_double_p, c_double_p, c_double_p]),
+    "vbnmf_engine_cluster_ids": (ctypes.c_int, [_VP, c_int32_p]),
     "vbnmf_engine_spmm": (ctypes.c_int, [_VP, _I32, c_double_p, c_double_p]),
     "vbnmf_layout_build": (ctypes.c_int, [_VP, _I64, _I64, _I32, _I32, _VPP, ctypes.POINTER(LayoutView)]),
     "vbnmf_layout_destroy": (None, [_VP]),

@@ -975,6 +975,23 @@ int vbnmf_engine_ml_get_state(vbnmf_engine *e, double *w, double *h)
     return VBNMF_OK;
 }
 
+int vbnmf_engine_cluster_ids(vbnmf_engine *e, int32_t *ids)
+{
+    if (!e || !ids) return fail(VBNMF_ERR_BAD_ARG, "NULL argument");
+    if (!e->ml_ready && !e->has_state) return fail(VBNMF_ERR_STATE, "cluster_ids before a state was loaded");
+    if (int rc = use_device(e)) return rc;
+    const double *h = e->ml_ready ? e->lh : e->eh;   // ML: the coefficient matrix itself; VB: its posterior mean E[H]
+    int32_t *d_ids = nullptr;
+    if (int rc = dev_alloc(&d_ids, (size_t)e->m)) return rc;
+    hipLaunchKernelGGL(k_argmax, dim3((unsigned)((e->m + 255) / 256)), dim3(256), 0, e->stream, h, e->m, e->r, e->R, d_ids);
+    hipError_t he = hipGetLastError();
+    if (he == hipSuccess) he = hipMemcpyAsync(ids, d_ids, (size_t)e->m * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+    (void)hipFree(d_ids);
+    if (he != hipSuccess) return fail(VBNMF_ERR_HIP, "cluster_ids failed: %s", hipGetErrorString(he));
+    return VBNMF_OK;
+}
+
 // ---------------------------------------------------------------- sparse products (truncated SVD of the svd2 initialiser)
 int vbnmf_engine_spmm(vbnmf_engine *e, int32_t transpose, const double *B, double *C)
 {

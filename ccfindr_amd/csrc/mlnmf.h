@@ -88,4 +88,20 @@ __global__ __launch_bounds__(1024) void k_ml_final(const double *__restrict__ bp
     }
 }
 
+// which.max(h[, j])[1] for every cell j (reference R/factorize.R:55-56, R/utils.R:906): 1-based index of the first
+// maximum among the r components.  NaN entries never win (R's which.max skips them); a column of NaNs gives 0.
+__global__ __launch_bounds__(256) void k_argmax(const double *__restrict__ h, int64_t m, int r, int R, int32_t *__restrict__ ids)
+{
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= m) return;
+    const double *row = h + (size_t)j * R;
+    int best = 0;
+    double bv = 0.0;
+    for (int k = 0; k < r; k++) {
+        const double v = row[k];
+        if (v == v && (best == 0 || v > bv)) { best = k + 1; bv = v; }
+    }
+    ids[j] = best;
+}
+
 }  // namespace vbnmf

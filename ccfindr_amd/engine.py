@@ -205,6 +205,12 @@ class VBEngine:
         N.check(self._lib.vbnmf_engine_ml_get_state(self._h, N.dptr(w), N.dptr(h)))
         return {k: v for k, v in (("ew", w), ("eh", h)) if v is not None}
 
+    def cluster_ids(self):
+        """1-based arg-max component of every cell (``which.max(h[, j])``) of the ML / VB state the engine holds."""
+        ids = np.empty(self.m, dtype=np.int32)
+        N.check(self._lib.vbnmf_engine_cluster_ids(self._h, ids.ctypes.data_as(N.c_int32_p)))
+        return ids
+
     # -- sparse products with the resident X (truncated SVD of the svd2 initialiser) ----------
     def spmm(self, B, transpose=False):
         """``X @ B.T`` (B: r x m -> n x r) or, with ``transpose``, ``B.T @ X`` (B: n x r -> r x m); drops any state."""

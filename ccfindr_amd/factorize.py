@@ -185,7 +185,7 @@ def factorize(mat, ranks=2, nrun=20, randomize=False, nsmpl=1, verbose=2, progre
                     for it in range(1, Itmax + 1):                                 # :196
                         lk0 = eng.ml_step()                                        # :197-198
                         if criterion == "connectivity":
-                            cid = cluster_ids(eng.ml_get_state(("eh",))["eh"])
+                            cid = (eng.cluster_ids() - 1) if hasattr(eng, "cluster_ids") else cluster_ids(eng.ml_get_state(("eh",))["eh"])
                             nchange = npair if it == 1 else connectivity_changes(cid0, cid, rank)   # :200-202
                             if verbose >= 3:
                                 say(f"{it} : likelihood =  {lk0} , connectivity change =  {nchange}")

@@ -235,6 +235,13 @@ int vbnmf_ml_update_csc(int64_t n, int64_t m, int32_t r, const int32_t *p, const
                         int32_t prior, double gamma_a, double gamma_b,
                         double *w, double *h, double *lk);
 
+/* Cluster of every cell from the coefficients the engine holds:
+ * ids[j] = which.max(h[, j])[1], 1-based, first maximum on ties (R/factorize.R:55-56 inside
+ * connectivity(), R/utils.R:906 cluster_id); h = the ML coefficient matrix, or E[H] of a VB
+ * state.  ids: m_local int32.  Saves the r x m download when only the labels are needed
+ * (the connectivity stopping criterion of factorize(), R/factorize.R:198-208). */
+int vbnmf_engine_cluster_ids(vbnmf_engine *e, int32_t *ids);
+
 /* ---------------------------------------------------------------------------------
  * Sparse products with the resident X, the two matrix-vector
  * blocks of a truncated SVD -- what irlba::irlba(mat, rank) computes for the svd2

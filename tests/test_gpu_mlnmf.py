@@ -265,3 +265,28 @@ def test_c3_full_size_against_stored_entries_oracle_and_monotone():
         assert lk >= prev - 1e-13 * abs(prev)
         prev = lk
     eng.close()
+
+
+def test_cluster_ids_on_device_and_connectivity_criterion():
+    """which.max over the resident coefficients (first maximum on ties, NaN skipped), and factorize() under
+    criterion = 'connectivity' (R/factorize.R:198-208) against the oracle's loop."""
+    import ccfindr_amd as C
+    from oracle import mlnmf_oracle as O
+    X = counts(50, 90, 0.8, seed=71)
+    w, h = uniform_state(50, 90, 4, seed=72)
+    h[:, 3] = [0.5, 0.9, 0.9, 0.1]                    # a tie: the first maximum wins
+    h[:, 4] = [np.nan, 0.2, 0.1, 0.05]                # NaN never wins
+    eng = C.VBEngine(C.CountMatrix(X), 4)
+    eng.ml_set_state(w, h)
+    ids = eng.cluster_ids()
+    want = np.array([np.nanargmax(h[:, j]) + 1 for j in range(90)])
+    assert ids.dtype == np.int32 and np.array_equal(ids, want) and ids[3] == 2 and ids[4] == 2
+    eng.close()
+    res = C.factorize(X, ranks=3, nrun=2, verbose=0, criterion="connectivity", ncnn_step=12, Itmax=400, seed=9)
+    rng = np.random.default_rng(9)
+    steps = []
+    for irun in range(2):
+        wh = O.init(50, 90, 3, rng)
+        run = O.factorize_run(lambda a, b: O.nmf_update_literal(X, a, b), X, wh, Itmax=400, criterion="connectivity", ncnn_step=12)
+        steps.append(run["it"])
+    assert res.nsteps[0] == steps
