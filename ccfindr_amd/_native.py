@@ -88,6 +88,7 @@ SIGNATURES = {
                                         c_double_p, c_double_p, c_double_p] + [_D] * 5 + [c_double_p] * 7),
     "vbnmf_engine_ml_set_state": (ctypes.c_int, [_VP, c_double_p, c_double_p]),
     "vbnmf_engine_ml_step": (ctypes.c_int, [_VP, _I32, _D, _D, c_double_p]),
+    "vbnmf_engine_ml_run": (ctypes.c_int, [_VP, _I32, _D, _D, _I32, _D, c_int32_p, c_double_p, c_int32_p, c_double_p, _I64]),
     "vbnmf_engine_ml_likelihood": (ctypes.c_int, [_VP, c_double_p]),
     "vbnmf_engine_ml_get_state": (ctypes.c_int, [_VP, c_double_p, c_double_p]),
     "vbnmf_ml_update_dense": (ctypes.c_int, [_I64, _I64, _I32, c_double_p, c_double_p, c_double_p, _I32, _D, _D,

@@ -340,7 +340,6 @@ int launch_sweep1(vbnmf_engine *e, bool gene_side)
 {
     SweepSide a = sweep_side_args(e, gene_side ? e->A : e->B, gene_side, gene_side ? e->epart : e->epart + e->n_wg);
     a.logterm = gene_side ? 0 : 1;
-    a.stop = nullptr;
     hipEvent_t t0 = gene_side ? e->ev0 : e->ev2, t1 = gene_side ? e->ev1 : e->ev3;
     if (e->timing) { HIPCHECK(hipEventRecord(t0, e->stream)); }
     int rc = VBNMF_ERR_BAD_ARG;
@@ -362,8 +361,9 @@ int launch_ml_update(vbnmf_engine *e, bool gene_side, int prior, double ga, doub
     const double *other_bp = gene_side ? e->bpH : e->bpW;
     double *f = gene_side ? e->lw : e->lh;
     double *bp = gene_side ? e->bpW : e->bpH;
+    const int32_t *stop = e->run_active ? &e->ctl->stop : nullptr;
     switch (e->R) {
-#define X(RR) case RR: hipLaunchKernelGGL((k_ml_update<RR>), dim3(kUpdateBlocks), dim3(kUpdateThreads), 0, e->stream, S.part, S.inv_ptr, S.inv_task, nmaj, e->r, other_bp, kUpdateBlocks, prior, ga, gb, eps, f, bp); break;
+#define X(RR) case RR: hipLaunchKernelGGL((k_ml_update<RR>), dim3(kUpdateBlocks), dim3(kUpdateThreads), 0, e->stream, S.part, S.inv_ptr, S.inv_task, nmaj, e->r, other_bp, kUpdateBlocks, prior, ga, gb, eps, f, bp, stop); break;
         VBNMF_FOR_EACH_R(X)
 #undef X
         default: return fail(VBNMF_ERR_BAD_ARG, "unsupported padded rank %d", e->R);
@@ -949,6 +949,78 @@ int vbnmf_engine_ml_step(vbnmf_engine *e, int32_t prior, double gamma_a, double 
     if (int rc = harvest_timing(e)) return rc;
     if (lk) *lk = e->h_out[0];
     return VBNMF_OK;
+}
+
+// Device-driven form of factorize()'s inner loop under criterion = 'likelihood' (reference R/factorize.R:194-213).
+int vbnmf_engine_ml_run(vbnmf_engine *e, int32_t prior, double gamma_a, double gamma_b, int32_t max_it, double tol,
+                        int32_t *it_out, double *lk_out, int32_t *reason_out, double *history, int64_t history_rows)
+{
+    if (!e) return fail(VBNMF_ERR_BAD_ARG, "engine handle is NULL");
+    if (!e->ml_ready) return fail(VBNMF_ERR_STATE, "ml_run before ml_set_state");
+    if (max_it < 1) return fail(VBNMF_ERR_BAD_ARG, "max_it must be >= 1");
+    if (history && history_rows < max_it) return fail(VBNMF_ERR_BAD_ARG, "history needs max_it doubles");
+    if (int rc = use_device(e)) return rc;
+    const double eps = 2.220446049250313e-16;
+
+    LoopCtl c{};
+    c.lk0 = -INFINITY;                                             // lkold <- -Inf (:193)
+    c.tol = tol; c.max_it = max_it;
+    double *d_hist = nullptr;
+    if (history) { if (int rc = dev_alloc(&d_hist, (size_t)max_it)) return rc; }
+    auto cleanup = [&](int rc) { e->run_active = false; (void)hipFree(d_hist); return rc; };
+    hipError_t he = hipMemcpyAsync(e->ctl, &c, sizeof c, hipMemcpyHostToDevice, e->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(e->stream);    // `c` is on this stack frame
+    if (he != hipSuccess) return cleanup(fail(VBNMF_ERR_HIP, "loading the loop control block failed: %s", hipGetErrorString(he)));
+    volatile double *ho = e->h_out;
+    ho[5] = 0.0; ho[6] = 0.0; ho[7] = 0.0;
+    e->run_active = true;
+    const bool timing = e->timing;
+    e->timing = false;                                             // event pairs cannot follow launches queued ahead
+    auto done_with = [&](int rc) { e->timing = timing; return cleanup(rc); };
+
+    const int batch = 8;
+    int queued = 0;
+    bool stopped = false;
+    while (!stopped) {
+        const int done = (int)ho[7];
+        while (queued < max_it && queued - done < 2 * batch) {
+            int rc = launch_ml_update(e, false, prior, gamma_a, gamma_b, eps);
+            if (!rc) rc = launch_sweep1(e, true);
+            if (!rc) rc = launch_ml_update(e, true, prior, gamma_a, gamma_b, eps);
+            if (!rc) rc = launch_sweep1(e, false);
+            if (rc) return done_with(rc);
+            switch (e->R) {
+#define X(RR) case RR: hipLaunchKernelGGL((k_ml_control<RR>), dim3(1), dim3(1024), 0, e->stream, e->bpW, e->bpH, kUpdateBlocks, e->epart + e->n_wg, (int64_t)e->n_wg, e->xlx, e->r, (double)e->n, (double)e->m, e->ctl, d_hist, e->h_out_dev); break;
+                VBNMF_FOR_EACH_R(X)
+#undef X
+                default: return done_with(fail(VBNMF_ERR_BAD_ARG, "unsupported padded rank %d", e->R));
+            }
+            if ((he = hipGetLastError()) != hipSuccess) return done_with(fail(VBNMF_ERR_HIP, "k_ml_control launch failed: %s", hipGetErrorString(he)));
+            queued++;
+        }
+        long spins = 0;
+        while (true) {
+            if (ho[6] != 0.0) { stopped = true; break; }
+            const int d2 = (int)ho[7];
+            if (d2 >= max_it) { stopped = true; break; }
+            if (queued < max_it && queued - d2 < 2 * batch) break;
+            if ((++spins & 0xFFFF) == 0) {
+                hipError_t q = hipStreamQuery(e->stream);
+                if (q != hipSuccess && q != hipErrorNotReady) return done_with(fail(VBNMF_ERR_HIP, "the loop failed on the device: %s", hipGetErrorString(q)));
+                if (q == hipSuccess && ho[6] == 0.0 && (int)ho[7] < queued) return done_with(fail(VBNMF_ERR_HIP, "the device went idle before the queued steps finished"));
+            }
+        }
+    }
+    he = hipStreamSynchronize(e->stream);
+    if (he == hipSuccess) he = hipMemcpy(&c, e->ctl, sizeof c, hipMemcpyDeviceToHost);
+    if (he == hipSuccess && history && c.it > 0) he = hipMemcpy(history, d_hist, (size_t)c.it * sizeof(double), hipMemcpyDeviceToHost);
+    if (he != hipSuccess) return done_with(fail(VBNMF_ERR_HIP, "reading the loop result failed: %s", hipGetErrorString(he)));
+    if (it_out) *it_out = c.it;
+    if (lk_out) *lk_out = c.lkh;
+    if (reason_out) *reason_out = c.reason;
+    e->h_out[0] = c.lkh;                                            // ml_likelihood() keeps answering for the pair held now
+    e->seq = 0.0; e->h_out[7] = 0.0;                                // the step path's sequence flag restarts
+    return done_with(VBNMF_OK);
 }
 
 int vbnmf_engine_ml_get_state(vbnmf_engine *e, double *w, double *h)

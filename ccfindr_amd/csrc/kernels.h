@@ -352,6 +352,7 @@ template <int R, bool WIDE, bool LOGTERM, int NT>
 __global__ __launch_bounds__(NT) void k_sweep1(const SweepSide S)
 {
     extern __shared__ double2 ldsG[];
+    if (S.stop && *S.stop) return;               // device-driven ML loop: the run has ended
     sweep_side<R, WIDE, LOGTERM, NT, LOGTERM ? 2 : 0>(S, ldsG);
 }
 

@@ -23,11 +23,12 @@ template <int R>
 __global__ __launch_bounds__(kUpdateThreads) void k_ml_update(
     const double *__restrict__ part, const int32_t *__restrict__ inv_ptr, const uint32_t *__restrict__ inv_task,
     int64_t nmaj, int r, const double *__restrict__ other_bp, int other_nb, int prior, double ga, double gb, double eps,
-    double *__restrict__ f, double *__restrict__ bp)
+    double *__restrict__ f, double *__restrict__ bp, const int32_t *__restrict__ stop)
 {
     constexpr int RB = kUpdateThreads / R;       // majors per pass
     __shared__ double s_other[R + 2];
     __shared__ double s_e[kUpdateThreads];
+    if (stop && *stop) return;                   // device-driven loop: the run has ended, leave the factors as they are
     const int t = threadIdx.x;
     bp_colsums(other_bp, other_nb, R + 2, s_other, kUpdateThreads);
     __syncthreads();
@@ -86,6 +87,41 @@ __global__ __launch_bounds__(1024) void k_ml_final(const double *__restrict__ bp
         __threadfence_system();
         reinterpret_cast<volatile double *>(out_host)[7] = seq;
     }
+}
+
+// Device-driven loop of factorize() under criterion = 'likelihood' (R/factorize.R:194-213): after each step the
+// likelihood, then `if (abs(lkold - lk0) < Tol * abs(lkold)) break ; lkold <- lk0` (:211-213; lkold starts at -Inf, so
+// the first pass never breaks; a NaN likelihood never satisfies the test either, as in R's host loop mirror).
+// LoopCtl: lk0 holds lkold, lkh the last likelihood.  history[it-1] = lk.  out_host = [lk, ., ., ., ., it, reason, it].
+template <int R>
+__global__ __launch_bounds__(1024) void k_ml_control(const double *__restrict__ bpW, const double *__restrict__ bpH, int nb,
+                                                     const double *__restrict__ epart, int64_t nepart, double xlx, int r,
+                                                     double n, double m, LoopCtl *ctl, double *__restrict__ history,
+                                                     double *__restrict__ out_host)
+{
+    if (ctl->stop) return;
+    __shared__ double sW[R + 2], sH[R + 2];
+    __shared__ double sm[1024];
+    bp_colsums(bpW, nb, R + 2, sW, 1024);
+    bp_colsums(bpH, nb, R + 2, sH, 1024);
+    const double data = block_vec_sum(epart, nepart, sm);
+    if (threadIdx.x != 0) return;
+    double cross = 0.0;
+    for (int k = 0; k < r; k++) cross += sW[k] * sH[k];
+    const double lk = ((data - cross) + xlx) / n / m;
+    const int it = ctl->it + 1;
+    const double lkold = ctl->lk0;
+    int reason = 0;
+    if (fabs(lkold - lk) < ctl->tol * fabs(lkold)) reason = 2;           // converged (:211)
+    else { ctl->lk0 = lk; if (it >= ctl->max_it) reason = 4; }
+    ctl->it = it; ctl->lkh = lk;
+    if (history) history[it - 1] = lk;
+    if (reason) { ctl->reason = reason; ctl->stop = 1; }
+    out_host[0] = lk;
+    out_host[5] = (double)it;
+    __threadfence_system();
+    reinterpret_cast<volatile double *>(out_host)[6] = (double)reason;
+    reinterpret_cast<volatile double *>(out_host)[7] = (double)it;
 }
 
 // which.max(h[, j])[1] for every cell j (reference R/factorize.R:55-56, R/utils.R:906): 1-based index of the first

@@ -193,6 +193,19 @@ class VBEngine:
         N.check(self._lib.vbnmf_engine_ml_step(self._h, int(bool(prior)), float(gamma_a), float(gamma_b), ctypes.byref(lk)))
         return lk.value
 
+    def ml_run(self, Itmax=10000, Tol=1e-5, prior=False, gamma_a=1.0, gamma_b=1.0, history=False):
+        """factorize()'s likelihood-criterion loop on the resident pair, driven by the device ->
+        ``{"it", "lk", "reason"[, "history"]}`` (reason 2 converged, 4 Itmax)."""
+        it, reason, lk = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_double()
+        hist = np.empty(int(Itmax)) if history else None
+        N.check(self._lib.vbnmf_engine_ml_run(self._h, int(bool(prior)), float(gamma_a), float(gamma_b), int(Itmax), float(Tol),
+                                              ctypes.byref(it), ctypes.byref(lk), ctypes.byref(reason), N.dptr(hist),
+                                              int(Itmax) if history else 0))
+        out = {"it": it.value, "lk": lk.value, "reason": reason.value}
+        if history:
+            out["history"] = hist[:it.value].copy()
+        return out
+
     def ml_likelihood(self):
         """likelihood(mat, w, h) of the pair the engine holds now."""
         lk = ctypes.c_double()

@@ -123,12 +123,14 @@ class MLResult:
 
 def factorize(mat, ranks=2, nrun=20, randomize=False, nsmpl=1, verbose=2, progress_bar=True, Itmax=10000,
               ncnn_step=40, criterion="likelihood", linkage="average", Tol=1e-5, store_connectivity=False,
-              seed=None, device=0, engine_factory=None):
+              seed=None, device=0, engine_factory=None, device_loop=True):
     """Maximum-likelihood NMF of a count matrix on the MI355X engine; reference R/factorize.R:140-320.
 
     ``mat``: genes x cells counts (dense array, scipy sparse, or ``CountMatrix``).  ``seed`` seeds the numpy
     Generator behind ``init`` and the ``randomize`` permutations.  ``engine_factory(count_matrix, rank)`` replaces
-    the engine constructor (the CPU tests of this loop pass a stand-in).  Returns ``MLResult``.
+    the engine constructor (the CPU tests of this loop pass a stand-in).  ``device_loop``: under
+    ``criterion='likelihood'`` (and ``verbose < 3``) the inner loop (:194-213) runs on the device
+    (``vbnmf_engine_ml_run``) instead of one call per iteration.  Returns ``MLResult``.
     """
     del progress_bar
     if isinstance(mat, CountMatrix):
@@ -182,7 +184,11 @@ def factorize(mat, ranks=2, nrun=20, randomize=False, nsmpl=1, verbose=2, progre
                     wh = init(nrow, ncol, rank, rng)                               # :192
                     eng.ml_set_state(wh["ew"], wh["eh"])
                     zstep, lkold, cid0, lk0, it = 0, -np.inf, None, np.nan, 0
-                    for it in range(1, Itmax + 1):                                 # :196
+                    on_device = device_loop and criterion == "likelihood" and verbose < 3 and hasattr(eng, "ml_run")
+                    if on_device:                                                  # the loop below, driven by the device
+                        run = eng.ml_run(Itmax=Itmax, Tol=Tol)
+                        it, lk0 = run["it"], run["lk"]
+                    for it in (() if on_device else range(1, Itmax + 1)):          # :196
                         lk0 = eng.ml_step()                                        # :197-198
                         if criterion == "connectivity":
                             cid = (eng.cluster_ids() - 1) if hasattr(eng, "cluster_ids") else cluster_ids(eng.ml_get_state(("eh",))["eh"])

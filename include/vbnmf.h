@@ -222,6 +222,13 @@ int vbnmf_update_csc(int64_t n, int64_t m, int32_t r, const int32_t *p, const in
  * --------------------------------------------------------------------------------- */
 int vbnmf_engine_ml_set_state(vbnmf_engine *e, const double *w, const double *h);
 int vbnmf_engine_ml_step(vbnmf_engine *e, int32_t prior, double gamma_a, double gamma_b, double *lk);
+/* factorize()'s inner loop under criterion = 'likelihood' (R/factorize.R:194-213) run by the device: up to
+ * max_it steps, break when abs(lkold - lk) < tol * abs(lkold) (lkold starts at -Inf), steps queued ahead of
+ * the GPU.  Outputs (any may be NULL): it = steps done, lk = likelihood of the last step, reason (2 converged,
+ * 4 max_it reached), history[it] = the likelihood after every step (history_rows >= max_it). */
+int vbnmf_engine_ml_run(vbnmf_engine *e, int32_t prior, double gamma_a, double gamma_b, int32_t max_it,
+                        double tol, int32_t *it, double *lk, int32_t *reason, double *history,
+                        int64_t history_rows);
 int vbnmf_engine_ml_likelihood(vbnmf_engine *e, double *lk);
 int vbnmf_engine_ml_get_state(vbnmf_engine *e, double *w, double *h);
 /* Stateless forms of the same step: nmf_updateR(x, w, h, n, m, r, prior, gamma.a, gamma.b)

@@ -290,3 +290,31 @@ def test_cluster_ids_on_device_and_connectivity_criterion():
         run = O.factorize_run(lambda a, b: O.nmf_update_literal(X, a, b), X, wh, Itmax=400, criterion="connectivity", ncnn_step=12)
         steps.append(run["it"])
     assert res.nsteps[0] == steps
+
+
+def test_device_driven_ml_loop_equals_host_stepped():
+    """vbnmf_engine_ml_run (factorize()'s likelihood-criterion loop on the device) against the same loop stepped from
+    the host: same iteration count, same likelihood history, same factors; and the golden stop iteration."""
+    import ccfindr_amd as C
+    z = np.load(os.path.join(GOLD, "ml_traj_120x200_r3.npz"))
+    eng = C.VBEngine(C.CountMatrix(z["X"]), 3)
+    eng.ml_set_state(z["w0"], z["h0"])
+    run = eng.ml_run(Itmax=2000, Tol=float(z["tol"]), history=True)
+    dev = eng.ml_get_state()
+    assert run["reason"] == 2 and run["it"] == int(z["it"]) and abs(run["lk"] / float(z["lk_stop"]) - 1) <= 1e-9
+    assert eng.ml_likelihood() == run["lk"] and run["history"].shape == (run["it"],) and run["history"][-1] == run["lk"]
+    eng.ml_set_state(z["w0"], z["h0"])
+    host = [eng.ml_step() for _ in range(run["it"])]
+    st = eng.ml_get_state()
+    assert np.array_equal(np.array(host), run["history"])            # the same kernels in the same order: bit for bit
+    assert np.array_equal(st["ew"], dev["ew"]) and np.array_equal(st["eh"], dev["eh"])
+    # Itmax reached before convergence
+    eng.ml_set_state(z["w0"], z["h0"])
+    run = eng.ml_run(Itmax=7, Tol=0.0)
+    assert run["reason"] == 4 and run["it"] == 7 and run["lk"] == host[6]
+    # the step path works again after a run
+    assert eng.ml_step() == host[7]
+    eng.close()
+    a = C.factorize(z["X"], ranks=3, nrun=2, verbose=0, Tol=1e-6, Itmax=600, seed=3, device_loop=True)
+    b = C.factorize(z["X"], ranks=3, nrun=2, verbose=0, Tol=1e-6, Itmax=600, seed=3, device_loop=False)
+    assert a.nsteps == b.nsteps and a.measure == b.measure and np.array_equal(a.basis[0], b.basis[0])
