@@ -102,8 +102,8 @@ def cpu_baseline(X, r, wh0, nsteps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--mode", choices=("restarts", "cells"), default="restarts")
     ap.add_argument("--small", action="store_true", help="2k x 5k smoke-sized workload (not the headline)")
     ap.add_argument("--cpu-steps", type=int, default=4)
