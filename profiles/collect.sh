@@ -9,7 +9,7 @@ TAG=${1:-r01}
 REPO=$PWD
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
-python3 bench.py --steps 200 --warmup 10 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 echo "bench done"
 export TMPDIR=/tmp
 cd /tmp
