@@ -109,6 +109,7 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=4)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-ml", action="store_true", help="skip the ML-NMF side measurement")
+    ap.add_argument("--rank", type=int, default=0, help="diagnostic: another rank on the same matrix (the metric is rank 10)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -132,6 +133,9 @@ def main():
         torch.cuda.synchronize()
 
     name, X, r = make_workload(args.small)
+    if args.rank > 0 and args.rank != r:
+        r = args.rank
+        name = name.replace("rank 10", f"rank {r} (diagnostic, not the headline rank)")
     n, m = X.shape
     nnz = int(X.nnz)
     M = C.CountMatrix(X)
