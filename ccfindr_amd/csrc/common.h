@@ -117,8 +117,9 @@ constexpr int kLdsReserveBytes = 4112;
 // without spilling: 4 waves/SIMD up to R = 4, 3 up to 10, 2 up to 26, 1 beyond (spills at 2 waves
 // made R = 32 ten times slower).
 constexpr int sweep_threads(int R) { return R <= 4 ? 1024 : (R <= 10 ? 768 : (R <= 26 ? 512 : 256)); }
-// Default block width / task length for a side at padded rank R; n_wg <= 0 picks the default (256).
-LayoutParams default_layout_params(int64_t n_major, int64_t n_minor, int R, int n_wg = 0);
+// Default block width / task length for a side at padded rank R with `nnz` stored entries (0: unknown, longest
+// tasks); n_wg <= 0 picks the default (256).
+LayoutParams default_layout_params(int64_t n_major, int64_t n_minor, int R, int n_wg = 0, int64_t nnz = 0);
 
 // Build the layout of `side` for columns [cb, ce) of X.
 int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const LayoutParams &lp, Layout &out);

@@ -534,7 +534,7 @@ int vbnmf_engine_create_part(const vbnmf_matrix *X, int64_t cb, int64_t ce, int6
     try {
         for (int side = 0; side < 2 && !rc; side++) {
             int64_t nmaj = side == 0 ? e->n : e->m, nmin = side == 0 ? e->m : e->n;
-            LayoutParams lp = default_layout_params(nmaj, nmin, e->R, e->n_wg);
+            LayoutParams lp = default_layout_params(nmaj, nmin, e->R, e->n_wg, X->M.colptr[ce] - X->M.colptr[cb]);
             std::shared_ptr<const Layout> shared;
             Layout own;
             const Layout *L = &own;

@@ -313,7 +313,7 @@ static int env_int(const char *name, int dflt)
     return atoi(s);
 }
 
-LayoutParams default_layout_params(int64_t n_major, int64_t n_minor, int R, int n_wg)
+LayoutParams default_layout_params(int64_t n_major, int64_t n_minor, int R, int n_wg, int64_t nnz)
 {
     (void)n_major;
     LayoutParams lp;
@@ -330,12 +330,22 @@ LayoutParams default_layout_params(int64_t n_major, int64_t n_minor, int R, int 
     c = (c + 7) & ~(int64_t)7;
     if (c > cmax) c = cmax;
     lp.block_width = (int32_t)c;
-    int ml = env_int("VBNMF_MAX_LEN", 256);
-    if (ml < kWidthQuantum) ml = kWidthQuantum;
-    lp.max_len = (ml + kWidthQuantum - 1) / kWidthQuantum * kWidthQuantum;
     if (n_wg <= 0) n_wg = env_int("VBNMF_NWG", 256);
     if (n_wg < 1) n_wg = 1;
     lp.n_wg = n_wg;
+    // Longest task.  A lane walks its task serially (~0.15 us per entry when its wave is alone on a SIMD), so on a
+    // small matrix 256-entry tasks leave a handful of waves running for 40 us while the rest of the chip idles:
+    // tasks are cut short enough that every wave of every workgroup can have work, up to the 256 that the
+    // headline size wants (shorter tasks there only add partial rows).  VBNMF_MAX_LEN overrides.
+    int ml = env_int("VBNMF_MAX_LEN", 0);
+    if (ml <= 0) {
+        const int64_t waves = (int64_t)n_wg * (sweep_threads(R) / kLanes);
+        // measured on 1 000 x 450, 2 000 x 5 000, 5 000 x 10 000 and the headline matrix: best near two entries per lane
+        // of every wave, not below 16
+        ml = nnz > 0 ? (int)std::max<int64_t>(16, std::min<int64_t>(256, 2 * nnz / (kLanes * waves) + 1)) : 256;
+    }
+    if (ml < kWidthQuantum) ml = kWidthQuantum;
+    lp.max_len = (ml + kWidthQuantum - 1) / kWidthQuantum * kWidthQuantum;
     lp.row_slots = lds_row_bytes(R) / 16;
     return lp;
 }
@@ -888,7 +898,8 @@ int vbnmf_layout_build(const vbnmf_matrix *X, int64_t col_begin, int64_t col_end
         int R = padded_rank(r);
         int64_t nmaj = side == 0 ? X->M.n : col_end - col_begin;
         int64_t nmin = side == 0 ? col_end - col_begin : X->M.n;
-        LayoutParams lp = default_layout_params(nmaj, nmin, R);
+        const bool range_ok = col_begin >= 0 && col_end <= X->M.m && col_begin < col_end;      // build_layout reports a bad range
+        LayoutParams lp = default_layout_params(nmaj, nmin, R, 0, range_ok ? X->M.colptr[col_end] - X->M.colptr[col_begin] : 0);
         int rc = build_layout(X->M, col_begin, col_end, side, lp, H->L);
         if (rc) { delete H; return rc; }
     } catch (const std::bad_alloc &) {

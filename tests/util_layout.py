@@ -39,6 +39,8 @@ def build_layout(M, side, r, cols=None):
 def reconstruct(view):
     """Dense [n_major, n_minor] matrix the layout encodes; checks the structural invariants on the way."""
     A = np.zeros((view["n_major"], view["n_minor"]))
+    nslot = np.zeros(A.shape, dtype=np.int64)          # slots per (major, minor)
+    npart = np.zeros(A.shape, dtype=np.int64)          # ... of which not a full 16383 piece
     C = view["block_width"]
     ntask = 0
     first_minor = {}
@@ -68,20 +70,18 @@ def reconstruct(view):
             assert (idx[~live] == 0).all()
             cols = blk * C + idx[live]
             assert (cols < min((blk + 1) * C, view["n_minor"])).all()
-            # any order (bank-conflict schedule); a minor repeats only when a count above the packed range was split,
-            # and then all but one of its pieces are full (16383)
-            assert (A[M, cols] == 0).all()                     # no entry stored twice across tasks
-            if np.unique(cols).size != cols.size:
-                assert not view["wide"]
-                for c in np.unique(cols):
-                    pieces = np.sort(val[live][cols == c])
-                    assert (pieces[1:] == 16383).all() or pieces.size == 1
+            # any order (bank-conflict schedule).  A (major, minor) pair occupies one slot, unless a count above the
+            # packed range was split: then all but one of its slots hold a full piece (16383) -- checked at the end.
             np.add.at(A, (np.full(cols.size, M), cols), val[live])
+            np.add.at(nslot, (np.full(cols.size, M), cols), 1)
+            np.add.at(npart, (np.full(cols.size, M), cols), (val[live] != 16383).astype(np.int64))
             first_minor[tid] = int(cols.min())
             lens.append(n_live)
         assert lens == sorted(lens, reverse=True)              # longest task first: width = first lane
         assert (w - lens[0]) < 8
     assert ntask == view["n_tasks"]
+    multi = nslot > 1
+    assert (npart[multi] <= 1).all() and (not multi.any() or not view["wide"])      # no entry stored twice
     # inverse index: every task exactly once, under its own major, in ascending minor order
     seen = np.zeros(view["n_slices"] * 64, dtype=np.int64)
     for M in range(view["n_major"]):
