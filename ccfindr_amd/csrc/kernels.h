@@ -634,31 +634,40 @@ __device__ inline double dev_trigamma(double x)
 }
 __device__ inline double dev_digamma1(double x) { double p, g; dev_psi_lgamma(x, &p, &g); return (x > 0.0) ? p : __builtin_nan(""); }
 
-// Returns 0, or 1 when the Newton iteration does not converge ("Hyper-parameter update failed to converge", :43).
-__device__ inline int dev_hyper_update(const int32_t *flags, const double *stats, double *hyper)
+// hyper_update (R/bayesian.R:2-53) by lanes 0 and 1 of a wave side by side: lane 0 iterates aw, lane 1 ah -- the two
+// Newton recurrences (:19-27) only meet in the convergence test (:37), which the lanes form by exchanging their
+// terms, so both run the same number of iterations as the sequential form and reach the same values.  A dependent fp64
+// chain (log, digamma, trigamma) costs microseconds on one lane; this halves it.
+// Returns 0, or 1 when the Newton iteration does not converge ("Hyper-parameter update failed to converge", :43);
+// lane 0 stores the four new hyper-parameters.
+__device__ inline int dev_hyper_update_pair(const int32_t *flags, const double *stats, double *hyper, int lane)
 {
     if (flags[0] + flags[1] + flags[2] + flags[3] == 0) return 0;                          // :4
-    double aw0 = hyper[0], ah0 = hyper[2];
-    const double lwm = stats[0], lhm = stats[1], ewm = stats[2], ehm = stats[3];           // :8-11
-    const double bw0 = hyper[1], bh0 = hyper[3];
-    double aw1 = aw0, ah1 = ah0;
+    double a0 = hyper[2 * lane];                           // aw (lane 0) or ah (lane 1)
+    const double b0 = hyper[2 * lane + 1];                 // bw or bh
+    const double lm = stats[lane], em = stats[2 + lane];   // mean log l, mean e of this side (:8-11)
+    const int fa = flags[2 * lane];
+    double a1 = a0;
+    int failed = 0;
     if (flags[0] + flags[2] > 0) {                                                         // :15
         int i = 1;
         while (i < 100) {                                                                  // Niter = 100 (:343)
-            double dw = flags[0] ? (log(aw0) - dev_digamma1(aw0) - ewm / bw0 + 1.0 + lwm - log(bw0)) / (1.0 / aw0 - dev_trigamma(aw0)) : 0.0;
-            double dh = flags[2] ? (log(ah0) - dev_digamma1(ah0) - ehm / bh0 + 1.0 + lhm - log(bh0)) / (1.0 / ah0 - dev_trigamma(ah0)) : 0.0;
-            aw1 = aw0 - dw; ah1 = ah0 - dh;
-            while (aw1 <= 0.0) { dw *= 0.5; aw1 = aw0 - dw; }                              // :28-31
-            while (ah1 <= 0.0) { dh *= 0.5; ah1 = ah0 - dh; }                              // :32-35
-            const double u = 1.0 - aw1 / aw0, v = 1.0 - ah1 / ah0;
-            if (u * u + v * v < 1e-3) break;                                               // Tol = 1e-3 (:344)
-            aw0 = aw1; ah0 = ah1; i++;
+            double d = fa ? (log(a0) - dev_digamma1(a0) - em / b0 + 1.0 + lm - log(b0)) / (1.0 / a0 - dev_trigamma(a0)) : 0.0;
+            a1 = a0 - d;
+            while (a1 <= 0.0) { d *= 0.5; a1 = a0 - d; }                                   // :28-35
+            const double u = 1.0 - a1 / a0;
+            const double uw = __shfl(u, 0, 64), uh = __shfl(u, 1, 64);
+            if (uw * uw + uh * uh < 1e-3) break;                                           // Tol = 1e-3 (:344)
+            a0 = a1; i++;
         }
-        if (i == 100) return 1;
+        if (i == 100) failed = 1;
     }
-    hyper[0] = aw1; hyper[1] = flags[1] ? ewm : bw0;                                       // :48-49
-    hyper[2] = ah1; hyper[3] = ehm;                                                        // :50-51 (both branches assign ehm)
-    return 0;
+    const double aw1 = __shfl(a1, 0, 64), ah1 = __shfl(a1, 1, 64);
+    if (lane == 0 && !failed) {
+        hyper[0] = aw1; hyper[1] = flags[1] ? stats[2] : hyper[1];                         // :48-49
+        hyper[2] = ah1; hyper[3] = stats[3];                                               // :50-51 (both branches assign ehm)
+    }
+    return failed;
 }
 
 // One block after each sweep of a device-driven loop: the reductions of k_final, then
@@ -677,7 +686,8 @@ __global__ __launch_bounds__(1024) void k_control(const double *__restrict__ bpW
     bp_colsums(bpW, nb, R + 2, sW, 1024);
     bp_colsums(bpH, nb, R + 2, sT, 1024);
     const double data = block_vec_sum(epart, nepart, sm);
-    if (threadIdx.x != 0) return;
+    const int lane = threadIdx.x;
+    if (lane > 1) return;                        // lanes 0 and 1 go on (the two Newton recurrences of hyper_update)
     double cross = 0.0, sew = 0.0, seh = 0.0;
     for (int k = 0; k < r; k++) { cross += sW[k] * sT[k]; sew += sW[k]; seh += sT[k]; }
     const double U = -cross - data - lgx + sW[R] + sT[R];
@@ -686,8 +696,9 @@ __global__ __launch_bounds__(1024) void k_control(const double *__restrict__ bpW
     const int it = ctl->it + 1;
     int reason = 0;
     if (it > ctl->n0 && it % ctl->dn == 0) {
-        if (dev_hyper_update(ctl->flags, st, ctl->hyper)) reason = 3;
+        if (dev_hyper_update_pair(ctl->flags, st, ctl->hyper, lane)) reason = 3;
     }
+    if (lane != 0) return;
     const double lk0 = ctl->lk0;
     if (!reason) {
         if (lkh != lkh) reason = 1;
