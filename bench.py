@@ -188,6 +188,17 @@ def main():
         if res["it"] != args.steps:
             raise SystemExit(f"device loop ran {res['it']} steps, expected {args.steps}")
         lkh_dev = res["lkh"]
+        # one more pass with the reference's default hyper.update = TRUE (n0 = 10, dn = 1), to
+        # show what the Newton updates of aw, ah on the device cost per step (reported, not `value`)
+        hyper_on = None
+        if world == 1:
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            res_h = eng.run(HYPER, Itmax=args.steps, Tol=0.0, n0=10, dn=1, flags=(True,) * 4)
+            torch.cuda.synchronize()
+            dt_h = time.perf_counter() - t1
+            hyper_on = {"value": res_h["it"] / dt_h, "unit": "iterations/s", "ms_per_step": 1e3 * dt_h / max(res_h["it"], 1),
+                        "steps": res_h["it"], "hyper_last": res_h["hyper"]}
 
     # The maximum-likelihood NMF step of factorize() (reference R/factorize.R:2-27 + :40-49)
     # on the same matrix and rank: K steps host-stepped (sweep timing) and K device-driven, reported beside the headline
@@ -286,6 +297,8 @@ def main():
         }
         out["host_stepped"] = {"value": host_value, "unit": "iterations/s", "ms_per_step": host_ms, "steps": args.steps,
                                "lkh_last": lkh}
+        if dt_dev is not None and hyper_on:
+            out["hyper_updates_on"] = hyper_on
         if ml:
             out["ml_nmf"] = ml
         if not args.no_cpu and world == 1:
