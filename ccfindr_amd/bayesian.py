@@ -17,6 +17,7 @@ count matrix itself and returns a plain result object holding the slots the refe
 from __future__ import annotations
 
 import math
+import threading
 import warnings
 from dataclasses import dataclass, field
 
@@ -227,17 +228,23 @@ def _bundle_rng(bundle, irun, rank):
     return np.random.default_rng(None if seed is None else [int(seed), int(irun), int(rank)])
 
 
+def _engine_key(bundle, rank):
+    # under `concurrent` > 1 each worker thread keeps its own engines: an engine serves one host thread at a time
+    return (threading.get_ident(), rank) if bundle.get("concurrent", 1) > 1 else rank
+
+
 def _make_engine(bundle, rank):
     """The engine of one rank.  Building one means cutting the tiled layout of X for that rank on the host (seconds
     at C3), so the restarts of a rank (``nrun`` > 1) share it: ``bundle["engines"]`` keeps one per rank until
     ``_close_engines``."""
     cache = bundle.get("engines")
-    if cache is not None and rank in cache:
-        return cache[rank]
+    key = _engine_key(bundle, rank)
+    if cache is not None and key in cache:
+        return cache[key]
     factory = bundle.get("engine_factory")
     eng = factory(bundle["mat"], rank) if factory is not None else VBEngine(bundle["mat"], rank, device=bundle.get("device", 0))
     if cache is not None:
-        cache[rank] = eng
+        cache[key] = eng
     return eng
 
 
@@ -386,7 +393,7 @@ def make_bundle(mat, ranks, nrun, verbose, initializer, Itmax, hyper_update, gam
 def vb_factorize(mat, ranks=2, nrun=1, verbose=2, progress_bar=True, initializer="random", Itmax=10000,
                  hyper_update=(True, True, True, True), gamma_a=1, gamma_b=1, Tol=1e-5,
                  hyper_update_n0=10, hyper_update_dn=1, connectivity=False, fudge=None, ncores=1,
-                 useC=True, unif_stop=True, seed=None, device=0, engine_factory=None, device_loop=True):
+                 useC=True, unif_stop=True, seed=None, device=0, engine_factory=None, device_loop=True, concurrent=1):
     """Bayesian NMF of a count matrix on the MI355X engine; reference R/bayesian.R:229-301.
 
     ``mat`` is the genes x cells count matrix (dense, scipy sparse, or ``CountMatrix``).
@@ -396,6 +403,11 @@ def vb_factorize(mat, ranks=2, nrun=1, verbose=2, progress_bar=True, initializer
     reference.  ``seed`` seeds the numpy Generator of the ``random`` initialiser (one stream
     per (run, rank)).  ``engine_factory(mat, rank)`` replaces the engine constructor (used by
     ``ccfindr_amd.parallel`` for cell-partitioned engines, and by the CPU tests of this loop).
+    ``concurrent`` > 1 keeps that many (run, rank) units in flight on the one GPU, each on its own engine and HIP
+    stream from its own host thread: on small matrices a step is latency bound (tens of microseconds with most of
+    the chip idle), so independent factorisations overlap almost for free.  Every unit draws from its own seeded
+    stream, so the result does not depend on ``concurrent``; with ``unif_stop`` a run's ranks beyond a constant
+    basis column are still computed (and then discarded, as the sharded driver does).
     """
     del progress_bar, useC, ncores
     if connectivity:
@@ -403,9 +415,20 @@ def vb_factorize(mat, ranks=2, nrun=1, verbose=2, progress_bar=True, initializer
     bundle = make_bundle(mat, ranks, nrun, verbose, initializer, Itmax, hyper_update, gamma_a, gamma_b, Tol,
                          hyper_update_n0, hyper_update_dn, fudge, unif_stop, seed, device, engine_factory)
     bundle["device_loop"] = bool(device_loop)      # False: step from the host (the loop below, literally)
-    bundle["engines"] = {} if nrun > 1 else None   # restarts of a rank reuse its engine (its layout of X)
+    bundle["concurrent"] = max(1, int(concurrent))
+    bundle["engines"] = {} if (nrun > 1 or bundle["concurrent"] > 1) else None   # restarts of a rank reuse its engine
     try:
-        vb = [vb_iterate(irun, bundle) for irun in range(1, nrun + 1)]           # :260-261
+        if bundle["concurrent"] > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            units = [(irun, int(r)) for irun in range(1, nrun + 1) for r in bundle["ranks"]]
+            units.sort(key=lambda u: -u[1])                                      # longest first
+            with ThreadPoolExecutor(max_workers=bundle["concurrent"]) as pool:
+                recs = list(pool.map(lambda u: vb_run_rank(u[0], u[1], bundle), units))
+            records = dict(zip(units, recs))
+            vb = [assemble_run({r: records[(irun, int(r))] for r in bundle["ranks"]}, [int(r) for r in bundle["ranks"]], unif_stop)
+                  for irun in range(1, nrun + 1)]
+        else:
+            vb = [vb_iterate(irun, bundle) for irun in range(1, nrun + 1)]       # :260-261
     finally:
         _close_engines(bundle)
     return select_best(vb, bundle["ranks"])
