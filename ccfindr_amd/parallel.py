@@ -126,11 +126,21 @@ class CellPartitionedEngine:
     def _allreduce(self):
         if self.world == 1:
             return
-        if self._stream_ctx is not None:
+        red = self._red
+        staged = getattr(red, "is_cuda", False) and self._dist.get_backend(self.group) != "nccl"
+        if staged:
+            # a backend that cannot reduce device memory (gloo: rehearsals of the multi-process path on one GPU):
+            # the buffer goes through the host, in order on the engine's stream
             with self._stream_ctx():
-                self._dist.all_reduce(self._red, op=self._dist.ReduceOp.SUM, group=self.group)
+                host = red.cpu()
+            self._dist.all_reduce(host, op=self._dist.ReduceOp.SUM, group=self.group)
+            with self._stream_ctx():
+                red.copy_(host)
+        elif self._stream_ctx is not None:
+            with self._stream_ctx():
+                self._dist.all_reduce(red, op=self._dist.ReduceOp.SUM, group=self.group)
         else:
-            self._dist.all_reduce(self._red, op=self._dist.ReduceOp.SUM, group=self.group)
+            self._dist.all_reduce(red, op=self._dist.ReduceOp.SUM, group=self.group)
 
     def set_state(self, lw, lh, eh):
         cb, ce = self.cols
