@@ -123,9 +123,17 @@ def main():
     import ccfindr_amd as C
     from ccfindr_amd import synth
 
+    # BENCH_BACKEND=gloo rehearses the multi-process paths with several ranks on ONE GPU (RCCL refuses two ranks on
+    # a device); BENCH_ONE_DEVICE=1 then puts every rank on cuda:0.  The driver's runs use neither.
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    if os.environ.get("BENCH_ONE_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     def barrier():
         if world > 1:
@@ -252,7 +260,8 @@ def main():
             ml["lk_rel_err_first_steps"] = max(abs(g / c - 1) for g, c in zip(ml_lk[:2], cpu_lk))
 
     if world > 1:
-        t = torch.tensor([dt, dt_dev if dt_dev is not None else 0.0], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt, dt_dev if dt_dev is not None else 0.0], dtype=torch.float64,
+                         device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0].item())
         if dt_dev is not None:
