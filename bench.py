@@ -8,11 +8,21 @@ vbnmf_update iteration (reference src/vbnmf_update.cpp:33-90, evidence included)
 device-resident state, with lkh and the four hyper statistics delivered to the host for every
 iteration, as the reference's caller needs them (reference R/bayesian.R:345-347).
 
-The K timed steps are measured twice: stepped from the host (vbnmf_engine_step: one call, one
-read-back per iteration -> `host_stepped`) and driven by the device (vbnmf_engine_run, the loop of
-vb_iterate with hyper_update and the stopping rule on the GPU and the per-step history written to
-pinned host memory -> `value`; this is the path ccfindr_amd.vb_factorize runs by default).  The
-roofline figures of k_sweep come from HIP events around its launches in the host-stepped pass.
+The K timed steps are measured on two loops, each as the MEDIAN of 5 back-to-back repeats of the K-step region (every
+repeat bracketed by a barrier + device synchronise; all five times are reported):
+  * driven by the device (vbnmf_engine_run: the loop of vb_iterate with hyper_update and the stopping rule on the GPU,
+    steps queued ahead, the per-step history -- lkh + 4 statistics of EVERY step -- written by the control kernel
+    straight into pinned host memory) -> `value`; this is the path ccfindr_amd.vb_factorize runs by default;
+  * stepped from the host (vbnmf_engine_step: one call and one read-back of lkh + statistics per iteration, SURVEY.md
+    section 8(d)'s literal metric) -> `host_stepped`.
+The roofline figures of k_sweep come from HIP events around its launches, on the engine's stream, in the host-stepped
+pass.  `roofline.traffic` is NOT measured in this run: it is the HBM byte count of the rocprofv3 --pmc passes kept
+under profiles/ (`traffic_source` names the file).
+
+CPU references timed in the same run, on rank 0 at N = 1: `cpu_baseline` = the oracle's stored-entries step with
+OpenMP on the box's cores (kind "port"); `cpu_reference_literal` = the oracle's LITERAL restatement of
+src/vbnmf_update.cpp (dense, same operation order, ONE thread -- the reference builds without OpenMP, src/Makevars:1-2)
+at a stated down-scale of the same matrix, with ns per matrix element and the extrapolation to the full size.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--mode restarts|cells] [--small]
 
@@ -99,6 +109,75 @@ def cpu_baseline(X, r, wh0, nsteps):
             "sample": f"{nsteps} full steps of the same workload (oracle update_csc, OpenMP x{cores})"}, lk
 
 
+def cpu_reference_literal(X, r, wh0, cells=2000, reps=2):
+    """The reference's own CPU form: the oracle's literal dense restatement of src/vbnmf_update.cpp:19-101 on ONE
+    thread, timed on the first `cells` cells of the workload (the dense form needs ~7 n*m temporaries: the full
+    20k x 50k matrix would take 56 GB and about a minute per step) and extrapolated per matrix element."""
+    from oracle import vbnmf_oracle as O
+    n, m = X.shape
+    cells = min(cells, m)
+    A = np.asfortranarray(X.tocsc()[:, :cells].toarray())
+    wh = {"lw": wh0["lw"], "lh": np.asfortranarray(wh0["lh"][:, :cells]), "eh": np.asfortranarray(wh0["eh"][:, :cells]),
+          "ew": wh0["ew"]}
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        wh = O.update_dense(A, wh, HYPER)
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": (1.0 / dt) * cells / m, "unit": "iterations/s", "cores": 1, "kind": "port",
+            "sample": f"{reps} steps of the literal dense restatement (oracle update_dense, 1 thread) on the first {cells} cells "
+                      f"of the same matrix ({n} x {cells}); value = measured rate x {cells}/{m} (cost is linear in n*m)",
+            "measured_it_per_s_at_sample": 1.0 / dt, "ns_per_matrix_element": 1e9 * dt / (n * cells),
+            "extrapolated_s_per_iteration_full_size": dt * m / cells}
+
+
+def cells_partitioned_sample(world, rank, local_rank, barrier, steps):
+    """BASELINE config C5 as a side measurement of an N > 1 run: ONE factorisation of a 30 000 x 200 000 (~5 % stored)
+    matrix at rank 20, cells partitioned over the N GPUs, the per-step all-reduce of [sw | rowSums(eh) | scalars] issued
+    by the library (RCCL over xGMI) inside the device-driven loop; strong scaling.  Rank 0 checks the first step's
+    evidence against the CPU oracle."""
+    import ccfindr_amd as C
+    from ccfindr_amd import synth
+    from ccfindr_amd.parallel import CellPartitionedEngine
+    n, m, r, k = 30000, 200000, 20, 20
+    depth = np.round(np.random.default_rng(5).lognormal(np.log(1950.0), 0.3, size=m)).astype(np.int64)
+    X = synth.fill_empty(synth.simulate_data(n, [m // k] * k, alpha0=0.1, seed=5, depth=depth), seed=5)
+    M = C.CountMatrix(X)
+    eng = CellPartitionedEngine(M, r, device=local_rank)
+    wh = synth.random_state(n, m, r, HYPER, seed=1005)
+    eng.set_state(wh["lw"], wh["lh"], wh["eh"])
+    first = eng.run(HYPER, Itmax=5, Tol=0.0, flags=(False,) * 4, history=True)      # warm-up; history[0] is checked below
+    times = []
+    for _ in range(3):
+        barrier()
+        t0 = time.perf_counter()
+        res = eng.run(HYPER, Itmax=steps, Tol=0.0, flags=(False,) * 4)
+        barrier()
+        times.append(time.perf_counter() - t0)
+    out = {"workload": f"C5 {n} x {m} (~5 % stored, nnz {int(X.nnz)}), rank {r}, cells partitioned {world}-way",
+           "loop": "device-driven (vbnmf_engine_run + vbnmf_comm: ncclAllReduce enqueued from C++ beside the cell-side sweep)",
+           "scaling": "strong", "steps": steps, "repeats_ms_per_step": [1e3 * t / steps for t in times],
+           "allreduce_bytes_per_step": 8 * (n * r + r + 4), "lkh_last": res["lkh"]}
+    eng.close()
+    if rank == 0:
+        from oracle import vbnmf_oracle as O
+        S = X.tocsc()
+        ref = O.update_csc(n, m, S.indptr, S.indices, S.data, wh, HYPER, nthreads=usable_cores())
+        out["lkh_rel_err_first_step_vs_cpu_oracle"] = abs(first["history"][0, 0] / ref["lkh"] - 1)
+    return out, times
+
+
+def timed_repeats(fn, barrier, repeats=5):
+    """`repeats` x [barrier, fn(), barrier] -> list of seconds."""
+    out = []
+    for _ in range(repeats):
+        barrier()
+        t0 = time.perf_counter()
+        fn()
+        barrier()
+        out.append(time.perf_counter() - t0)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -172,13 +251,17 @@ def main():
         gpu_lk.append(lkh)
 
     base_eng = getattr(eng, "engine", eng)
+    REPEATS = 5
+    last = {}
+
+    def host_pass():
+        for _ in range(args.steps):
+            last["lkh"], _ = step()
+
     base_eng.timing_enable(True)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        lkh, _ = step()
-    barrier()
-    dt = time.perf_counter() - t0
+    host_times = timed_repeats(host_pass, barrier, REPEATS)
+    dt = float(np.median(host_times))
+    lkh = last["lkh"]
     sweep_ms, sweep_cnt = base_eng.timing_get()
 
     # The same K steps with the loop driven by the device (vbnmf_engine_run: the product's default path,
@@ -186,16 +269,18 @@ def main():
     # steps queued ahead, lkh + the four statistics of EVERY step still delivered to the host through the history.
     # This is `value`; the host-stepped rate of the loop above is reported beside it.
     dt_dev = None
-    if hasattr(eng, "run"):
+    dev_times = None
+    if hasattr(eng, "run") and getattr(eng, "native", True):
         base_eng.timing_enable(False)
-        barrier()
-        t1 = time.perf_counter()
-        res = eng.run(HYPER, Itmax=args.steps, Tol=0.0, n0=10, dn=1, flags=(False,) * 4, history=True)
-        barrier()
-        dt_dev = time.perf_counter() - t1
-        if res["it"] != args.steps:
-            raise SystemExit(f"device loop ran {res['it']} steps, expected {args.steps}")
-        lkh_dev = res["lkh"]
+
+        def dev_pass():
+            last["res"] = eng.run(HYPER, Itmax=args.steps, Tol=0.0, n0=10, dn=1, flags=(False,) * 4, history=True)
+            if last["res"]["it"] != args.steps:
+                raise SystemExit(f"device loop ran {last['res']['it']} steps, expected {args.steps}")
+
+        dev_times = timed_repeats(dev_pass, barrier, REPEATS)
+        dt_dev = float(np.median(dev_times))
+        lkh_dev = last["res"]["lkh"]
         # one more pass with the reference's default hyper.update = TRUE (n0 = 10, dn = 1), to
         # show what the Newton updates of aw, ah on the device cost per step (reported, not `value`)
         hyper_on = None
@@ -260,12 +345,15 @@ def main():
             ml["lk_rel_err_first_steps"] = max(abs(g / c - 1) for g, c in zip(ml_lk[:2], cpu_lk))
 
     if world > 1:
-        t = torch.tensor([dt, dt_dev if dt_dev is not None else 0.0], dtype=torch.float64,
+        # MAX over ranks of every repeat, then the median of those
+        t = torch.tensor([host_times, dev_times if dev_times is not None else [0.0] * REPEATS], dtype=torch.float64,
                          device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t[0].item())
-        if dt_dev is not None:
-            dt_dev = float(t[1].item())
+        host_times = [float(v) for v in t[0].tolist()]
+        dt = float(np.median(host_times))
+        if dev_times is not None:
+            dev_times = [float(v) for v in t[1].tolist()]
+            dt_dev = float(np.median(dev_times))
 
     if rank == 0:
         bytes_iter, bytes_sweep = algorithmic_bytes(n, m, r, nnz)
@@ -278,13 +366,16 @@ def main():
         sweep_s = (sweep_ms / max(sweep_cnt, 1)) * 1e-3
         achieved = bytes_sweep / sweep_s / 1e9 if sweep_cnt else None
         info = base_eng.layout_info()
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tpath) and not args.small:
-            try:
-                traffic = json.load(open(tpath)).get("sweep_hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic, traffic_source = None, None
+        for tname in ("r02_traffic.json", "r01_traffic.json"):          # newest rocprofv3 --pmc summary kept under profiles/
+            tpath = os.path.join(ROOT, "profiles", tname)
+            if os.path.exists(tpath) and not args.small and args.rank in (0, 10):
+                try:
+                    traffic = json.load(open(tpath)).get("sweep_hbm_bytes_per_launch")
+                    traffic_source = f"profiles/{tname} (rocprofv3 --pmc passes of an earlier run of this command; not measured in this run)"
+                    break
+                except Exception:
+                    traffic = None
         out = {
             "metric": "VB-NMF update iterations/sec (20k x 50k sparse counts, rank 10)",
             "value": value, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -292,9 +383,11 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": name, "n_genes": n, "n_cells": m, "nnz": nnz, "rank": r,
                        "mode": args.mode if world > 1 else "single", "hyper": "fixed aw=bw=ah=bh=1",
-                       "loop": loop, "lkh_last": lkh_dev if dt_dev is not None else lkh},
+                       "loop": loop, "lkh_last": lkh_dev if dt_dev is not None else lkh,
+                       "timing": f"median of {REPEATS} repeats of the {args.steps}-step region"},
             "roofline": {"bound": "hbm", "kernel": "k_sweep", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                         "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": bytes_sweep, "kernel_ms": sweep_s * 1e3,
                          "streamed_bytes_per_launch": info["stream_bytes_per_step"]},
             # SURVEY.md section 8(d) asks for both fractions: algorithmic flops = 10 r per stored entry
@@ -304,8 +397,9 @@ def main():
             "iteration_roofline": {"bytes_iter": bytes_iter, "achieved_GBs": bytes_iter * (value / units_per_step) / 1e9,
                                    "frac": bytes_iter * (value / units_per_step) / 1e9 / HBM_PEAK_GBS},
         }
+        out["repeats_ms_per_step"] = [1e3 * t / args.steps for t in (dev_times if dev_times is not None else host_times)]
         out["host_stepped"] = {"value": host_value, "unit": "iterations/s", "ms_per_step": host_ms, "steps": args.steps,
-                               "lkh_last": lkh}
+                               "lkh_last": lkh, "repeats_ms_per_step": [1e3 * t / args.steps for t in host_times]}
         if dt_dev is not None and hyper_on:
             out["hyper_updates_on"] = hyper_on
         if ml:
@@ -314,9 +408,41 @@ def main():
             wh_cpu = synth.random_state(n, m, r, HYPER, seed=1003)
             cb, cpu_lk = cpu_baseline(X, r, wh_cpu, ncheck)
             out["cpu_baseline"] = cb
+            out["cpu_reference_literal"] = cpu_reference_literal(X, r, wh_cpu)
             k = min(len(cpu_lk), len(gpu_lk))
             if k:
                 out["elbo_rel_err_first_steps"] = max(abs(g / c - 1) for g, c in zip(gpu_lk[:k], cpu_lk[:k]))
+    # N > 1, default mode: after the headline (independent restarts, no collective) one C5-shaped cell-partitioned
+    # factorisation is run on the same N GPUs, so that the RCCL path of the library is measured on hardware too.  It can
+    # only hang where the fabric does, so the headline line is safe behind a watchdog that prints it and leaves.
+    if world > 1 and args.mode == "restarts" and backend == "nccl" and not args.small and not os.environ.get("BENCH_NO_CELLS"):
+        import threading
+
+        def give_up():
+            if rank == 0:
+                out["cells_partitioned"] = {"error": "timed out (watchdog 420 s)"}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(420.0, give_up)
+        dog.daemon = True
+        dog.start()
+        try:
+            eng.close()
+            cp, times = cells_partitioned_sample(world, rank, local_rank, barrier, max(50, min(args.steps, 300)))
+            t = torch.tensor(times, dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            med = float(np.median(t.tolist()))
+            cp["value"] = cp["steps"] / med
+            cp["unit"] = "iterations/s"
+            cp["ms_per_step"] = 1e3 * med / cp["steps"]
+            if rank == 0:
+                out["cells_partitioned"] = cp
+        except Exception as exc:                                   # noqa: BLE001 -- the headline must still be printed
+            if rank == 0:
+                out["cells_partitioned"] = {"error": f"{type(exc).__name__}: {exc}"}
+        dog.cancel()
+    if rank == 0:
         print(json.dumps(out), flush=True)
 
     eng.close()

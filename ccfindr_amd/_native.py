@@ -23,6 +23,7 @@ c_uint32_p = ctypes.POINTER(ctypes.c_uint32)
 
 OK, ERR_BAD_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_STATE = range(6)
 MAX_RANK = 32
+COMM_ID_BYTES = 128
 
 
 class VBNMFError(RuntimeError):
@@ -75,6 +76,16 @@ SIGNATURES = {
     "vbnmf_engine_state_finish": (ctypes.c_int, [_VP]),
     "vbnmf_engine_run": (ctypes.c_int, [_VP, c_double_p, _D, _I32, _D, _I32, _I32, c_int32_p, c_int32_p, c_double_p,
                                         c_double_p, c_int32_p, c_double_p, _I64]),
+    "vbnmf_comm_unique_id": (ctypes.c_int, [_VP, _I64]),
+    "vbnmf_comm_create": (ctypes.c_int, [_VP, _I64, _I32, _I32, _I32, _VPP]),
+    "vbnmf_comm_create_local": (ctypes.c_int, [_I32, _I32, _VPP]),
+    "vbnmf_comm_info": (ctypes.c_int, [_VP, c_int32_p, c_int32_p, c_int32_p]),
+    "vbnmf_comm_destroy": (None, [_VP]),
+    "vbnmf_engine_attach_comm": (ctypes.c_int, [_VP, _VP]),
+    "vbnmf_engine_allreduce": (ctypes.c_int, [_VP]),
+    "vbnmf_group_state_finish": (ctypes.c_int, [_VP]),
+    "vbnmf_group_run": (ctypes.c_int, [_VP, c_double_p, _D, _I32, _D, _I32, _I32, c_int32_p, c_int32_p, c_double_p,
+                                       c_double_p, c_int32_p, c_double_p, _I64]),
     "vbnmf_engine_get_state": (ctypes.c_int, [_VP] + [c_double_p] * 6),
     "vbnmf_engine_get_stream": (ctypes.c_int, [_VP, _VPP]),
     "vbnmf_engine_set_stream": (ctypes.c_int, [_VP, _VP]),

@@ -130,6 +130,11 @@ def hyper_update(hyper_update, wh, hyper, Niter=100, Tol=1e-4):
                   / (1 / aw0 - _trigamma(aw0))) if flags[0] else 0.0
             dh = ((math.log(ah0) - _digamma(ah0) - ehm / bh0 + 1 + lhm - math.log(bh0))
                   / (1 / ah0 - _trigamma(ah0))) if flags[2] else 0.0
+            # A non-finite Newton step (a -inf mean log: fudge = 0 and a shape small enough for exp(psi) to underflow)
+            # makes the reference's halving loops below spin for ever; it is reported as the failure of :43 instead,
+            # as the device loop does (kernels.h dev_hyper_update_pair).
+            if not (math.isfinite(dw) and math.isfinite(dh)):
+                raise RuntimeError("Hyper-parameter update failed to converge")
             aw1, ah1 = aw0 - dw, ah0 - dh
             while aw1 <= 0:                                      # :28-31
                 dw /= 2

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -22,6 +23,7 @@
 #include <new>
 
 #include "common.h"
+#include "comm.h"
 #include "kernels.h"
 #include "mlnmf.h"
 
@@ -35,6 +37,8 @@ using namespace vbnmf;
     } while (0)
 
 namespace {
+
+constexpr int kHostOut = 16;          // doubles in the pinned result block of an engine
 
 // The layout's arrays on the device.  Engines made from a cached layout (same matrix, same geometry, same device)
 // share one of these; the per-engine part is DeviceSide::part.
@@ -105,9 +109,20 @@ struct vbnmf_engine {
     double *bpW = nullptr, *bpH = nullptr;   // [kUpdateBlocks][R+2] block partials of the two updates
     double *red = nullptr;            // [n*R | R+4]  (partitioned engines only use the first part)
     int64_t red_count = 0;
+    double *red_g = nullptr;          // same shape: receive side of the all-reduce in a device-driven partitioned loop
+    const double *red_in = nullptr;   // what the W update and the control kernel read: red (reduced in place by the
+                                      // caller) or red_g (out of place, so that steps queued past the stop stay no-ops)
+    vbnmf_comm *comm = nullptr;       // attached communicator (not owned)
+    int comm_rank = 0;
+    hipStream_t cstream = nullptr;    // the all-reduces of a partitioned loop are enqueued here, beside the cell-side sweep
+    std::vector<hipEvent_t> ev_ring;  // events ordering the two streams, cycled (a step uses 3)
+    size_t ev_next = 0;
     double *d_out = nullptr;          // [8]
-    double *h_out = nullptr;          // pinned, device-visible [8]; [7] = sequence flag
+    double *h_out = nullptr;          // pinned, device-visible [kHostOut]; [7] = sequence flag; [8..12] = hyper, lk0 of a device-driven loop
     double *h_out_dev = nullptr;      // device address of h_out
+    double *h_hist = nullptr;         // pinned, device-visible per-step history of the device-driven loops (grown on demand)
+    double *h_hist_dev = nullptr;
+    size_t h_hist_count = 0;
     double seq = 0.0;
     LogTabEntry *logtab = nullptr;    // [128] ln table of the sweep
     LoopCtl *ctl = nullptr;           // control block of the device-driven loop
@@ -201,11 +216,11 @@ int prepare_sweep_kernel(const void *fn)
 template <int R, bool WIDE, int NT>
 int launch_sweep_t(vbnmf_engine *e, const SweepSide &a, const SweepSide &b)
 {
-    static bool attr_set[16] = {false};
+    static std::atomic<bool> attr_set[16];
     const void *fn = (const void *)k_sweep<R, WIDE, NT>;
-    if (e->device >= 16 || !attr_set[e->device]) {
+    if (e->device >= 16 || !attr_set[e->device].load(std::memory_order_acquire)) {
         if (int rc = prepare_sweep_kernel(fn)) return rc;
-        if (e->device < 16) attr_set[e->device] = true;
+        if (e->device < 16) attr_set[e->device].store(true, std::memory_order_release);
     }
     const unsigned grid = (unsigned)e->n_wg;
     hipLaunchKernelGGL((k_sweep<R, WIDE, NT>), dim3(grid), dim3(NT), e->lds_bytes, e->stream, a, b);
@@ -247,11 +262,12 @@ int launch_update(vbnmf_engine *e, bool gene_side, double a, double b, double fu
     const int side = gene_side ? 0 : 1;
     const bool dense = gene_side && e->partitioned;               // statistics already summed into `red`
     const DeviceSide &S = gene_side ? e->A : e->B;
-    const double *acc = dense ? e->red : S.part;
+    const double *redin = e->red_in ? e->red_in : e->red;
+    const double *acc = dense ? redin : S.part;
     const int32_t *inv_ptr = dense ? nullptr : S.inv_ptr;
     const uint32_t *inv_task = dense ? nullptr : S.inv_task;
     const int64_t nmaj = gene_side ? e->n : e->m;
-    const double *other = dense ? e->red + (size_t)e->n * e->R : nullptr;
+    const double *other = dense ? redin + (size_t)e->n * e->R : nullptr;
     const double *other_bp = dense ? nullptr : (gene_side ? e->bpH : e->bpW);
     const int other_nb = dense ? 0 : kUpdateBlocks;
     double *l = gene_side ? e->lw : e->lh, *ll = gene_side ? e->llw : e->llh;
@@ -312,18 +328,27 @@ int launch_pack(vbnmf_engine *e)
 }
 
 // ---- ML-NMF (mlnmf.h): single-side sweeps and the multiplicative updates ----
-template <int R, bool WIDE, bool LOGTERM, int NT>
+template <int R, bool WIDE, bool LOGTERM, int NT, bool VB = false>
 int launch_sweep1_t(vbnmf_engine *e, const SweepSide &a)
 {
-    static bool attr_set[16] = {false};
-    const void *fn = (const void *)k_sweep1<R, WIDE, LOGTERM, NT>;
-    if (e->device >= 16 || !attr_set[e->device]) {
+    static std::atomic<bool> attr_set[16];
+    const void *fn = (const void *)k_sweep1<R, WIDE, LOGTERM, NT, VB>;
+    if (e->device >= 16 || !attr_set[e->device].load(std::memory_order_acquire)) {
         if (int rc = prepare_sweep_kernel(fn)) return rc;
-        if (e->device < 16) attr_set[e->device] = true;
+        if (e->device < 16) attr_set[e->device].store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL((k_sweep1<R, WIDE, LOGTERM, NT>), dim3((unsigned)e->n_wg), dim3(NT), e->lds_bytes, e->stream, a);
+    hipLaunchKernelGGL((k_sweep1<R, WIDE, LOGTERM, NT, VB>), dim3((unsigned)e->n_wg), dim3(NT), e->lds_bytes, e->stream, a);
     HIPCHECK(hipGetLastError());
     return VBNMF_OK;
+}
+
+// One side of the VB sweep alone (cell-partitioned device loop): gene side with the log term, cell side without.
+template <int R>
+int launch_vb_side_r(vbnmf_engine *e, const SweepSide &a, bool gene_side)
+{
+    constexpr int NT = sweep_threads(R);
+    if (e->wide) return gene_side ? launch_sweep1_t<R, true, true, NT, true>(e, a) : launch_sweep1_t<R, true, false, NT, true>(e, a);
+    return gene_side ? launch_sweep1_t<R, false, true, NT, true>(e, a) : launch_sweep1_t<R, false, false, NT, true>(e, a);
 }
 
 template <int R>
@@ -352,6 +377,19 @@ int launch_sweep1(vbnmf_engine *e, bool gene_side)
     if (rc) return rc;
     if (e->timing) { HIPCHECK(hipEventRecord(t1, e->stream)); (gene_side ? e->ev_recorded : e->ev2_recorded) = true; }
     return VBNMF_OK;
+}
+
+int launch_vb_side(vbnmf_engine *e, bool gene_side)
+{
+    SweepSide a = sweep_side_args(e, gene_side ? e->A : e->B, gene_side, gene_side ? e->epart : e->epart + e->n_wg);
+    int rc = VBNMF_ERR_BAD_ARG;
+    switch (e->R) {
+#define X(RR) case RR: rc = launch_vb_side_r<RR>(e, a, gene_side); break;
+        VBNMF_FOR_EACH_R(X)
+#undef X
+        default: return fail(VBNMF_ERR_BAD_ARG, "unsupported padded rank %d", e->R);
+    }
+    return rc;
 }
 
 int launch_ml_update(vbnmf_engine *e, bool gene_side, int prior, double ga, double gb, double eps)
@@ -389,11 +427,11 @@ int launch_ml_final(vbnmf_engine *e)
 template <int R, bool WIDE, int NT>
 int launch_spmm_t(vbnmf_engine *e, const SweepSide &a)
 {
-    static bool attr_set[16] = {false};
+    static std::atomic<bool> attr_set[16];
     const void *fn = (const void *)k_spmm<R, WIDE, NT>;
-    if (e->device >= 16 || !attr_set[e->device]) {
+    if (e->device >= 16 || !attr_set[e->device].load(std::memory_order_acquire)) {
         if (int rc = prepare_sweep_kernel(fn)) return rc;
-        if (e->device < 16) attr_set[e->device] = true;
+        if (e->device < 16) attr_set[e->device].store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL((k_spmm<R, WIDE, NT>), dim3((unsigned)e->n_wg), dim3(NT), e->lds_bytes, e->stream, a);
     HIPCHECK(hipGetLastError());
@@ -486,12 +524,20 @@ void vbnmf_engine_destroy(vbnmf_engine *e)
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (e->cstream) (void)hipStreamSynchronize(e->cstream);
+    if (e->comm) {
+        for (vbnmf_engine *&q : e->comm->members) if (q == e) q = nullptr;
+        e->comm->tables_ready = false;
+    }
     free_side(e->A); free_side(e->B);
     (void)hipFree(e->lw); (void)hipFree(e->llw); (void)hipFree(e->ew); (void)hipFree(e->dw);
     (void)hipFree(e->lh); (void)hipFree(e->llh); (void)hipFree(e->eh); (void)hipFree(e->dh);
     (void)hipFree(e->epart); (void)hipFree(e->bpW); (void)hipFree(e->bpH);
-    (void)hipFree(e->red); (void)hipFree(e->d_out); (void)hipFree(e->dbg); (void)hipFree(e->logtab); (void)hipFree(e->ctl);
+    (void)hipFree(e->red); (void)hipFree(e->red_g); (void)hipFree(e->d_out);
+    for (hipEvent_t ev : e->ev_ring) (void)hipEventDestroy(ev);
+    if (e->cstream) (void)hipStreamDestroy(e->cstream); (void)hipFree(e->dbg); (void)hipFree(e->logtab); (void)hipFree(e->ctl);
     if (e->h_out) (void)hipHostFree(e->h_out);
+    if (e->h_hist) (void)hipHostFree(e->h_hist);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     if (e->ev2) (void)hipEventDestroy(e->ev2);
@@ -528,6 +574,13 @@ int vbnmf_engine_create_part(const vbnmf_matrix *X, int64_t cb, int64_t ce, int6
     e->n_wg = n_cu;                      // one persistent workgroup per CU
     if (const char *sv = getenv("VBNMF_NWG")) { int v = atoi(sv); if (v > 0) e->n_wg = v; }
     e->partitioned = (ce - cb) != m_global;
+    if (e->partitioned && !getenv("VBNMF_NWG")) {
+        // A partition's sweep leaves a few CUs free: its workgroups own all 160 KB of a CU's LDS, so the all-reduce
+        // kernels that should run BESIDE the cell-side sweep could not start on a chip filled by it.
+        int spare = 8;
+        if (const char *sv = getenv("VBNMF_COMM_CUS")) spare = atoi(sv);
+        if (spare >= 0 && e->n_wg - spare >= 8) e->n_wg -= spare;
+    }
     int rc = VBNMF_OK;
     auto bail = [&](int code) { vbnmf_engine_destroy(e); return code; };
 
@@ -572,14 +625,14 @@ int vbnmf_engine_create_part(const vbnmf_matrix *X, int64_t cb, int64_t ce, int6
         (rc = dev_alloc(&e->red, (size_t)e->red_count)) || (rc = dev_alloc(&e->d_out, 8)))
         return bail(rc);
     hipError_t he;
-    if ((he = hipHostMalloc((void **)&e->h_out, 8 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess ||
+    if ((he = hipHostMalloc((void **)&e->h_out, kHostOut * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess ||
         (he = hipHostGetDevicePointer((void **)&e->h_out_dev, e->h_out, 0)) != hipSuccess ||
         (he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)) != hipSuccess ||
         (he = hipEventCreate(&e->ev0)) != hipSuccess || (he = hipEventCreate(&e->ev1)) != hipSuccess ||
         (he = hipEventCreate(&e->ev2)) != hipSuccess || (he = hipEventCreate(&e->ev3)) != hipSuccess)
         return bail(fail(VBNMF_ERR_HIP, "engine setup failed: %s", hipGetErrorString(he)));
     e->own_stream = true;
-    std::memset(e->h_out, 0, 8 * sizeof(double));
+    std::memset(e->h_out, 0, kHostOut * sizeof(double));
     if (getenv("VBNMF_DEBUG_TIMES")) {
         e->dbg_count = 2 * (size_t)e->n_wg * (2 + 2 * (e->NT / 64));
         if ((rc = dev_alloc(&e->dbg, e->dbg_count))) return bail(rc);
@@ -733,82 +786,446 @@ int vbnmf_engine_step(vbnmf_engine *e, double aw, double bw, double ah, double b
     return vbnmf_engine_step_finish(e, lkh, stats);
 }
 
-// Device-driven form of the per-rank loop of vb_iterate (reference R/bayesian.R:336-352).
-int vbnmf_engine_run(vbnmf_engine *e, double *hyper, double fudge, int32_t max_it, double tol, int32_t n0, int32_t dn,
-                     const int32_t *flags, int32_t *it_out, double *lk0_out, double *lkh_out, int32_t *reason_out,
-                     double *history, int64_t history_rows)
+// ---------------------------------------------------------------- device-driven loops
+}  // extern "C"
+
+namespace {
+
+// Pinned, device-visible history of a device-driven loop (k_control / k_ml_control write one row per step straight
+// into host memory); kept by the engine and grown on demand, so a run allocates nothing.
+int ensure_history(vbnmf_engine *e, size_t doubles)
 {
-    if (!e || !hyper || !flags) return fail(VBNMF_ERR_BAD_ARG, "NULL argument");
-    if (e->partitioned) return fail(VBNMF_ERR_STATE, "the device-driven loop needs an unpartitioned engine");
-    if (!e->has_state || !e->stats_ready) return fail(VBNMF_ERR_STATE, "run before set_state");
-    if (e->step_pending) return fail(VBNMF_ERR_STATE, "run between step_local and step_finish");
+    if (doubles <= e->h_hist_count) return VBNMF_OK;
+    if (e->h_hist) {
+        HIPCHECK(hipStreamSynchronize(e->stream));
+        (void)hipHostFree(e->h_hist);
+        e->h_hist = nullptr; e->h_hist_dev = nullptr; e->h_hist_count = 0;
+    }
+    const size_t want = std::max<size_t>(doubles, 9 * 1024);
+    hipError_t he = hipHostMalloc((void **)&e->h_hist, want * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent);
+    if (he == hipSuccess) he = hipHostGetDevicePointer((void **)&e->h_hist_dev, e->h_hist, 0);
+    if (he != hipSuccess) {
+        (void)hipGetLastError();
+        if (e->h_hist) { (void)hipHostFree(e->h_hist); e->h_hist = nullptr; }
+        return fail(VBNMF_ERR_OOM, "pinned history buffer (%zu bytes): %s", want * sizeof(double), hipGetErrorString(he));
+    }
+    e->h_hist_count = want;
+    return VBNMF_OK;
+}
+
+// What a partitioned engine needs beside its own stream: the stream the all-reduces go on, the receive buffer, and
+// a ring of events (three per step, steps queued at most two batches ahead: 96 never wraps onto a pending one).
+int ensure_comm_resources(vbnmf_engine *e)
+{
+    if (!e->cstream) HIPCHECK(hipStreamCreateWithFlags(&e->cstream, hipStreamNonBlocking));
+    if (!e->red_g) { if (int rc = dev_alloc(&e->red_g, (size_t)e->red_count)) return rc; }
+    while (e->ev_ring.size() < 96) {
+        hipEvent_t ev;
+        HIPCHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        e->ev_ring.push_back(ev);
+    }
+    return VBNMF_OK;
+}
+
+hipEvent_t next_event(vbnmf_engine *e)
+{
+    hipEvent_t ev = e->ev_ring[e->ev_next];
+    e->ev_next = (e->ev_next + 1) % e->ev_ring.size();
+    return ev;
+}
+
+int rccl_check(ncclResult_t r, const char *what)
+{
+    if (r == ncclSuccess) return VBNMF_OK;
+    RcclApi &api = rccl_api();
+    return fail(VBNMF_ERR_HIP, "%s failed: %s", what, api.GetErrorString ? api.GetErrorString(r) : "RCCL error");
+}
+
+int launch_control(vbnmf_engine *e, double *hist_dev, bool reduced)
+{
+    const int64_t nep = 2 * (int64_t)e->n_wg;
+    const double *tail = reduced ? e->red_g + (size_t)e->n * e->R : nullptr;
+    const double *small = reduced ? e->red_g + (size_t)e->n * e->R + e->R + 2 : nullptr;
+    switch (e->R) {
+#define X(RR) case RR: hipLaunchKernelGGL((k_control<RR>), dim3(1), dim3(1024), 0, e->stream, e->bpW, e->bpH, kUpdateBlocks, e->epart, nep, e->lgx, e->r, (double)e->n, (double)e->m_global, e->ctl, hist_dev, e->h_out_dev, tail, small); break;
+        VBNMF_FOR_EACH_R(X)
+#undef X
+        default: return fail(VBNMF_ERR_BAD_ARG, "unsupported padded rank %d", e->R);
+    }
+    HIPCHECK(hipGetLastError());
+    return VBNMF_OK;
+}
+
+// The engines one device-driven loop advances together: a single engine, or the partition engines of a local group.
+struct LoopGroup {
+    vbnmf_engine **e;
+    int count;
+    vbnmf_comm *comm;      // null: one unpartitioned engine
+};
+
+// Device pointer tables of a local group's send / receive buffers (built once all members are attached).
+int group_tables(vbnmf_comm *c)
+{
+    if (c->tables_ready) return VBNMF_OK;
+    const int P = (int)c->members.size();
+    std::vector<const double *> sb(P), ss(P);
+    std::vector<double *> rb(P), rs(P);
+    for (int p = 0; p < P; p++) {
+        vbnmf_engine *e = c->members[p];
+        if (int rc = ensure_comm_resources(e)) return rc;
+        const size_t off = (size_t)e->n * e->R + e->R + 2;
+        sb[p] = e->red; rb[p] = e->red_g; ss[p] = e->red + off; rs[p] = e->red_g + off;
+    }
+    if (int rc = dev_alloc(&c->d_send_big, (size_t)P)) return rc;
+    if (int rc = dev_alloc(&c->d_send_small, (size_t)P)) return rc;
+    if (int rc = dev_alloc(&c->d_recv_big, (size_t)P)) return rc;
+    if (int rc = dev_alloc(&c->d_recv_small, (size_t)P)) return rc;
+    HIPCHECK(hipMemcpy(c->d_send_big, sb.data(), P * sizeof(void *), hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(c->d_send_small, ss.data(), P * sizeof(void *), hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(c->d_recv_big, rb.data(), P * sizeof(void *), hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(c->d_recv_small, rs.data(), P * sizeof(void *), hipMemcpyHostToDevice));
+    c->tables_ready = true;
+    return VBNMF_OK;
+}
+
+// One step of the device-driven VB loop, queued on every engine of the group.
+//   unpartitioned : k_update(W) k_update(H) k_sweep(both sides) k_control
+//   partitioned   : k_update(W <- reduced statistics) k_update(H) | gene-side sweep, k_pack, k_tail_h | event
+//                   -> comm stream: all-reduce [swsum | rowSum(eh) | 2 scalars]     (RCCL, or k_group_sum)
+//                   || main stream: cell-side sweep, k_tail_data | event
+//                   -> comm stream: all-reduce [data term | sum lgamma(x+1)] | event -> main stream: k_control
+// so the n*R-double exchange travels while the cell-side sweep runs and only the two-double
+// one sits between the sweep and the control kernel.  The all-reduces are out of place (red -> red_g): steps queued
+// past the stop leave `red` untouched, so repeating them reproduces the same sums.
+int queue_vb_step(const LoopGroup &G, double fudge, bool hist)
+{
+    if (!G.comm) {
+        vbnmf_engine *e = G.e[0];
+        int rc = launch_update(e, true, 0, 0, fudge, e->ctl);
+        if (!rc) rc = launch_update(e, false, 0, 0, fudge, e->ctl);
+        if (!rc) rc = launch_sweep(e);
+        if (!rc) rc = launch_control(e, hist ? e->h_hist_dev : nullptr, false);
+        return rc;
+    }
+    vbnmf_comm *c = G.comm;
+    const int P = G.count;
+    vbnmf_engine *L = G.e[0];                                  // leader: owner of the comm stream used by a local group
+    const int64_t nbig = L->n * L->R + L->R + 2;
+    hipEvent_t evA[64], evB[64];
+    for (int p = 0; p < P; p++) {
+        vbnmf_engine *e = G.e[p];
+        int rc = launch_update(e, true, 0, 0, fudge, e->ctl);
+        if (!rc) rc = launch_update(e, false, 0, 0, fudge, e->ctl);
+        if (!rc) rc = launch_vb_side(e, true);
+        if (rc) return rc;
+        const int64_t cnt = e->n * e->R;
+        hipLaunchKernelGGL(k_pack, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, e->stream, e->A.part, e->A.inv_ptr, e->A.inv_task, e->n, e->R, e->red);
+        HIPCHECK(hipGetLastError());
+        hipLaunchKernelGGL(k_tail_h, dim3(1), dim3(1024), 0, e->stream, e->bpH, kUpdateBlocks, e->R, e->red + cnt, &e->ctl->stop);
+        HIPCHECK(hipGetLastError());
+        evA[p] = next_event(e);
+        HIPCHECK(hipEventRecord(evA[p], e->stream));
+    }
+    if (c->kind == 0) {
+        HIPCHECK(hipStreamWaitEvent(L->cstream, evA[0], 0));
+        if (int rc = rccl_check(rccl_api().AllReduce(L->red, L->red_g, (size_t)nbig, ncclDouble, ncclSum, c->nc, L->cstream), "ncclAllReduce")) return rc;
+    } else {
+        for (int p = 0; p < P; p++) HIPCHECK(hipStreamWaitEvent(L->cstream, evA[p], 0));
+        hipLaunchKernelGGL(k_group_sum, dim3((unsigned)((nbig + 255) / 256)), dim3(256), 0, L->cstream, c->d_send_big, c->d_recv_big, P, nbig);
+        HIPCHECK(hipGetLastError());
+    }
+    for (int p = 0; p < P; p++) {
+        vbnmf_engine *e = G.e[p];
+        if (int rc = launch_vb_side(e, false)) return rc;
+        hipLaunchKernelGGL(k_tail_data, dim3(1), dim3(1024), 0, e->stream, e->epart, 2 * (int64_t)e->n_wg, e->lgx, e->red + nbig, &e->ctl->stop);
+        HIPCHECK(hipGetLastError());
+        evB[p] = next_event(e);
+        HIPCHECK(hipEventRecord(evB[p], e->stream));
+    }
+    hipEvent_t evD = next_event(L);
+    if (c->kind == 0) {
+        HIPCHECK(hipStreamWaitEvent(L->cstream, evB[0], 0));
+        if (int rc = rccl_check(rccl_api().AllReduce(L->red + nbig, L->red_g + nbig, 2, ncclDouble, ncclSum, c->nc, L->cstream), "ncclAllReduce")) return rc;
+    } else {
+        for (int p = 0; p < P; p++) HIPCHECK(hipStreamWaitEvent(L->cstream, evB[p], 0));
+        hipLaunchKernelGGL(k_group_sum, dim3(1), dim3(256), 0, L->cstream, c->d_send_small, c->d_recv_small, P, (int64_t)2);
+        HIPCHECK(hipGetLastError());
+    }
+    HIPCHECK(hipEventRecord(evD, L->cstream));
+    for (int p = 0; p < P; p++) {
+        vbnmf_engine *e = G.e[p];
+        HIPCHECK(hipStreamWaitEvent(e->stream, evD, 0));
+        if (int rc = launch_control(e, hist && p == 0 ? e->h_hist_dev : nullptr, true)) return rc;
+    }
+    return VBNMF_OK;
+}
+
+// Host side of a device-driven loop.  Steps are queued in batches of eight, two batches ahead of the device, and batch
+// b + 2 is queued exactly when the loop has not stopped at or before the last step of batch b -- a function of the
+// device's (replicated) decisions alone, never of when this host happened to look.  Every process of a partitioned run
+// therefore queues the same number of steps, i.e. the same sequence of collectives.  The host reads the pinned result
+// block of engine 0: [5] = steps done, [6] = reason (raised after [5]), [7] = steps done (raised last).
+template <class QueueStep>
+int drive_loop(vbnmf_engine *e0, int max_it, QueueStep &&queue_step)
+{
+    volatile double *ho = e0->h_out;
+    const int B = 8;
+    int queued = 0;
+    auto queue_batch = [&]() -> int {
+        for (int q = 0; q < B && queued < max_it; q++, queued++)
+            if (int rc = queue_step()) return rc;
+        return VBNMF_OK;
+    };
+    if (int rc = queue_batch()) return rc;
+    if (int rc = queue_batch()) return rc;
+    for (int b = 0;; b++) {
+        const int target = (int)std::min<int64_t>((int64_t)(b + 1) * B, max_it);
+        for (long spins = 1; ho[6] == 0.0 && (int)ho[7] < target; spins++) {
+            if ((spins & 0xFFFF) == 0) {
+                hipError_t q = hipStreamQuery(e0->stream);
+                if (q != hipSuccess && q != hipErrorNotReady) return fail(VBNMF_ERR_HIP, "the loop failed on the device: %s", hipGetErrorString(q));
+                if (q == hipSuccess && ho[6] == 0.0 && (int)ho[7] < queued) return fail(VBNMF_ERR_HIP, "the device went idle before the queued steps finished");
+            }
+        }
+        if (ho[6] != 0.0 && (int)ho[5] <= target) break;        // stopped inside a batch that is complete
+        if (target >= max_it) break;
+        if (int rc = queue_batch()) return rc;
+    }
+    return VBNMF_OK;
+}
+
+int run_group(const LoopGroup &G, double *hyper, double fudge, int32_t max_it, double tol, int32_t n0, int32_t dn,
+              const int32_t *flags, int32_t *it_out, double *lk0_out, double *lkh_out, int32_t *reason_out,
+              double *history, int64_t history_rows)
+{
+    if (!hyper || !flags) return fail(VBNMF_ERR_BAD_ARG, "NULL argument");
     if (max_it < 1 || dn < 1) return fail(VBNMF_ERR_BAD_ARG, "max_it and dn must be >= 1");
     if (history && history_rows < max_it) return fail(VBNMF_ERR_BAD_ARG, "history needs max_it rows of 9 doubles");
-    if (int rc = use_device(e)) return rc;
+    for (int p = 0; p < G.count; p++) {
+        vbnmf_engine *e = G.e[p];
+        if (!e->has_state || !e->stats_ready) return fail(VBNMF_ERR_STATE, "run before set_state (or before the state exchange of a partitioned engine)");
+        if (e->step_pending) return fail(VBNMF_ERR_STATE, "run between step_local and step_finish");
+    }
+    vbnmf_engine *e0 = G.e[0];
+    if (int rc = use_device(e0)) return rc;
+    if (history) { if (int rc = ensure_history(e0, (size_t)max_it * 9)) return rc; }
 
     LoopCtl c{};
     for (int q = 0; q < 4; q++) { c.hyper[q] = hyper[q]; c.flags[q] = flags[q] ? 1 : 0; }
     c.lk0 = 0.0;                                                   // :336
     c.tol = tol; c.max_it = max_it; c.n0 = n0; c.dn = dn;
-    double *d_hist = nullptr;
-    if (history) { if (int rc = dev_alloc(&d_hist, (size_t)max_it * 9)) return rc; }
-    auto cleanup = [&](int rc) { e->run_active = false; (void)hipFree(d_hist); return rc; };
-    hipError_t he = hipMemcpyAsync(e->ctl, &c, sizeof c, hipMemcpyHostToDevice, e->stream);
-    if (he != hipSuccess) return cleanup(fail(VBNMF_ERR_HIP, "hipMemcpyAsync failed: %s", hipGetErrorString(he)));
-    he = hipStreamSynchronize(e->stream);                          // `c` is on this stack frame
-    if (he != hipSuccess) return cleanup(fail(VBNMF_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(he)));
-    volatile double *ho = e->h_out;
-    ho[5] = 0.0; ho[6] = 0.0; ho[7] = 0.0;
-    e->run_active = true;
-
-    // Steps are queued ahead of the device (two batches deep) so the host never sits on the critical
-    // path; kernels of steps queued beyond the break return at once.
-    const int batch = 8;
-    const int64_t nep = 2 * (int64_t)e->n_wg;
-    int queued = 0;
-    bool stopped = false;
-    while (!stopped) {
-        const int done = (int)ho[7];
-        while (queued < max_it && queued - done < 2 * batch) {
-            int rc = launch_update(e, true, 0, 0, fudge, e->ctl);
-            if (!rc) rc = launch_update(e, false, 0, 0, fudge, e->ctl);
-            if (!rc) rc = launch_sweep(e);
-            if (rc) return cleanup(rc);
-            switch (e->R) {
-#define X(RR) case RR: hipLaunchKernelGGL((k_control<RR>), dim3(1), dim3(1024), 0, e->stream, e->bpW, e->bpH, kUpdateBlocks, e->epart, nep, e->lgx, e->r, (double)e->n, (double)e->m_global, e->ctl, d_hist, e->h_out_dev); break;
-                VBNMF_FOR_EACH_R(X)
-#undef X
-                default: return cleanup(fail(VBNMF_ERR_BAD_ARG, "unsupported padded rank %d", e->R));
-            }
-            if ((he = hipGetLastError()) != hipSuccess) return cleanup(fail(VBNMF_ERR_HIP, "k_control launch failed: %s", hipGetErrorString(he)));
-            queued++;
+    std::vector<bool> timing(G.count);
+    for (int p = 0; p < G.count; p++) {
+        vbnmf_engine *e = G.e[p];
+        timing[p] = e->timing;
+        e->timing = false;                                         // event pairs cannot follow launches queued ahead
+        e->ev_recorded = false; e->ev2_recorded = false;
+        hipLaunchKernelGGL(k_ctl_init, dim3(1), dim3(1), 0, e->stream, e->ctl, c);
+        if (G.comm) {                                              // the reduced statistics of the loaded state
+            e->red_in = e->red_g;
+            (void)hipMemcpyAsync(e->red_g, e->red, (size_t)e->red_count * sizeof(double), hipMemcpyDeviceToDevice, e->stream);
         }
-        // wait for progress: a reason code, or the device catching up with the queue
-        long spins = 0;
-        while (true) {
-            if (ho[6] != 0.0) { stopped = true; break; }
-            const int d2 = (int)ho[7];
-            if (d2 >= max_it) { stopped = true; break; }
-            if (queued < max_it && queued - d2 < 2 * batch) break;          // room to queue more
-            if ((++spins & 0xFFFF) == 0) {
-                hipError_t q = hipStreamQuery(e->stream);
-                if (q != hipSuccess && q != hipErrorNotReady) return cleanup(fail(VBNMF_ERR_HIP, "the loop failed on the device: %s", hipGetErrorString(q)));
-                if (q == hipSuccess && ho[6] == 0.0 && (int)ho[7] < queued) return cleanup(fail(VBNMF_ERR_HIP, "the device went idle before the queued steps finished"));
-            }
-        }
+        volatile double *ho = e->h_out;
+        ho[5] = 0.0; ho[6] = 0.0; ho[7] = 0.0;
+        e->run_active = true;
     }
-    he = hipStreamSynchronize(e->stream);
-    if (he != hipSuccess) return cleanup(fail(VBNMF_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(he)));
-    he = hipMemcpy(&c, e->ctl, sizeof c, hipMemcpyDeviceToHost);
-    if (he == hipSuccess && history && c.it > 0) he = hipMemcpy(history, d_hist, (size_t)c.it * 9 * sizeof(double), hipMemcpyDeviceToHost);
-    if (he != hipSuccess) return cleanup(fail(VBNMF_ERR_HIP, "reading the loop result failed: %s", hipGetErrorString(he)));
-    for (int q = 0; q < 4; q++) hyper[q] = c.hyper[q];
-    if (it_out) *it_out = c.it;
-    if (lk0_out) *lk0_out = c.lk0;
-    if (lkh_out) *lkh_out = c.lkh;
-    if (reason_out) *reason_out = c.reason;
-    e->seq = 0.0; e->h_out[7] = 0.0;                                // the step path's sequence flag restarts
+    auto cleanup = [&](int rc) {
+        for (int p = 0; p < G.count; p++) {
+            vbnmf_engine *e = G.e[p];
+            (void)hipStreamSynchronize(e->stream);
+            if (e->cstream) (void)hipStreamSynchronize(e->cstream);
+            if (G.comm) {                                          // host-stepped calls read the reduced statistics from `red`
+                (void)hipMemcpy(e->red, e->red_g, (size_t)e->red_count * sizeof(double), hipMemcpyDeviceToDevice);
+                e->red_in = nullptr;
+            }
+            e->run_active = false; e->timing = timing[p];
+            e->seq = 0.0; e->h_out[7] = 0.0;                       // the step path's sequence flag restarts
+        }
+        return rc;
+    };
+    hipError_t he = hipGetLastError();
+    if (he != hipSuccess) return cleanup(fail(VBNMF_ERR_HIP, "loading the loop control block failed: %s", hipGetErrorString(he)));
+
+    int rc = drive_loop(e0, max_it, [&]() { return queue_vb_step(G, fudge, history != nullptr); });
+    if (rc) return cleanup(rc);
+    for (int p = 0; p < G.count; p++) {
+        he = hipStreamSynchronize(G.e[p]->stream);
+        if (he == hipSuccess && G.e[p]->cstream) he = hipStreamSynchronize(G.e[p]->cstream);
+        if (he != hipSuccess) return cleanup(fail(VBNMF_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(he)));
+    }
+    const double *ho = e0->h_out;                                  // written by the last live k_control
+    const int it = (int)ho[5];
+    for (int q = 0; q < 4; q++) hyper[q] = ho[8 + q];
+    if (it_out) *it_out = it;
+    if (lk0_out) *lk0_out = ho[12];
+    if (lkh_out) *lkh_out = ho[0];
+    if (reason_out) *reason_out = (int)ho[6];
+    if (history && it > 0) std::memcpy(history, e0->h_hist, (size_t)it * 9 * sizeof(double));
     return cleanup(VBNMF_OK);
+}
+
+}  // namespace
+
+extern "C" {
+
+// Device-driven form of the per-rank loop of vb_iterate (reference R/bayesian.R:336-352).
+int vbnmf_engine_run(vbnmf_engine *e, double *hyper, double fudge, int32_t max_it, double tol, int32_t n0, int32_t dn,
+                     const int32_t *flags, int32_t *it_out, double *lk0_out, double *lkh_out, int32_t *reason_out,
+                     double *history, int64_t history_rows)
+{
+    if (!e) return fail(VBNMF_ERR_BAD_ARG, "NULL argument");
+    LoopGroup G{&e, 1, nullptr};
+    if (e->partitioned) {
+        if (!e->comm || e->comm->kind != 0)
+            return fail(VBNMF_ERR_STATE, "the device-driven loop of a partitioned engine needs an RCCL communicator (vbnmf_engine_attach_comm), or vbnmf_group_run for a local group");
+        if (int rc = use_device(e)) return rc;
+        if (int rc = ensure_comm_resources(e)) return rc;
+        G.comm = e->comm;
+    }
+    return run_group(G, hyper, fudge, max_it, tol, n0, dn, flags, it_out, lk0_out, lkh_out, reason_out, history, history_rows);
+}
+
+// ---------------------------------------------------------------- communicators (comm.h)
+int vbnmf_comm_unique_id(void *id, int64_t bytes)
+{
+    if (!id || bytes < (int64_t)sizeof(ncclUniqueId)) return fail(VBNMF_ERR_BAD_ARG, "the id buffer needs %d bytes", (int)sizeof(ncclUniqueId));
+    RcclApi &api = rccl_api();
+    if (!api.error.empty()) return fail(VBNMF_ERR_NO_DEVICE, "%s", api.error.c_str());
+    ncclUniqueId u;
+    if (int rc = rccl_check(api.GetUniqueId(&u), "ncclGetUniqueId")) return rc;
+    std::memcpy(id, &u, sizeof u);
+    return VBNMF_OK;
+}
+
+int vbnmf_comm_create(const void *id, int64_t bytes, int32_t nranks, int32_t rank, int32_t device, vbnmf_comm **out)
+{
+    if (!out) return fail(VBNMF_ERR_BAD_ARG, "out pointer is NULL");
+    *out = nullptr;
+    if (!id || bytes < (int64_t)sizeof(ncclUniqueId)) return fail(VBNMF_ERR_BAD_ARG, "the id buffer needs %d bytes", (int)sizeof(ncclUniqueId));
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(VBNMF_ERR_BAD_ARG, "rank %d is outside [0, %d)", rank, nranks);
+    if (int rc = check_device(device)) return rc;
+    RcclApi &api = rccl_api();
+    if (!api.error.empty()) return fail(VBNMF_ERR_NO_DEVICE, "%s", api.error.c_str());
+    HIPCHECK(hipSetDevice(device));
+    ncclUniqueId u;
+    std::memcpy(&u, id, sizeof u);
+    vbnmf_comm *c = new (std::nothrow) vbnmf_comm();
+    if (!c) return fail(VBNMF_ERR_OOM, "out of host memory");
+    c->kind = 0; c->nranks = nranks; c->rank = rank; c->device = device;
+    if (int rc = rccl_check(api.CommInitRank(&c->nc, nranks, u, rank), "ncclCommInitRank")) { delete c; return rc; }
+    *out = c;
+    return VBNMF_OK;
+}
+
+int vbnmf_comm_create_local(int32_t nranks, int32_t device, vbnmf_comm **out)
+{
+    if (!out) return fail(VBNMF_ERR_BAD_ARG, "out pointer is NULL");
+    *out = nullptr;
+    if (nranks < 1 || nranks > 64) return fail(VBNMF_ERR_BAD_ARG, "a local group holds 1..64 partitions");
+    if (int rc = check_device(device)) return rc;
+    vbnmf_comm *c = new (std::nothrow) vbnmf_comm();
+    if (!c) return fail(VBNMF_ERR_OOM, "out of host memory");
+    c->kind = 1; c->nranks = nranks; c->rank = 0; c->device = device;
+    *out = c;
+    return VBNMF_OK;
+}
+
+void vbnmf_comm_destroy(vbnmf_comm *c)
+{
+    if (!c) return;
+    for (vbnmf_engine *e : c->members) if (e && e->comm == c) e->comm = nullptr;
+    if (c->kind == 0 && c->nc) (void)rccl_api().CommDestroy(c->nc);
+    (void)hipFree(c->d_send_big); (void)hipFree(c->d_send_small); (void)hipFree(c->d_recv_big); (void)hipFree(c->d_recv_small);
+    delete c;
+}
+
+int vbnmf_comm_info(const vbnmf_comm *c, int32_t *nranks, int32_t *rank, int32_t *kind)
+{
+    if (!c) return fail(VBNMF_ERR_BAD_ARG, "communicator handle is NULL");
+    if (nranks) *nranks = c->nranks;
+    if (rank) *rank = c->rank;
+    if (kind) *kind = c->kind;
+    return VBNMF_OK;
+}
+
+int vbnmf_engine_attach_comm(vbnmf_engine *e, vbnmf_comm *c)
+{
+    if (!e || !c) return fail(VBNMF_ERR_BAD_ARG, "NULL argument");
+    if (e->comm) return fail(VBNMF_ERR_STATE, "the engine already has a communicator");
+    if (e->device != c->device) return fail(VBNMF_ERR_BAD_ARG, "engine on device %d, communicator on device %d", e->device, c->device);
+    if (c->kind == 0 && !c->members.empty()) return fail(VBNMF_ERR_STATE, "an RCCL communicator serves one engine per process");
+    if (c->kind == 1 && (int)c->members.size() >= c->nranks) return fail(VBNMF_ERR_STATE, "the local group is full");
+    if (c->kind == 1 && !c->members.empty() && (c->members[0]->n != e->n || c->members[0]->R != e->R || c->members[0]->m_global != e->m_global))
+        return fail(VBNMF_ERR_BAD_ARG, "partition engines of one group must share genes, rank and the global cell count");
+    if (int rc = use_device(e)) return rc;
+    if (int rc = ensure_comm_resources(e)) return rc;
+    e->comm = c;
+    e->comm_rank = c->kind == 0 ? c->rank : (int)c->members.size();
+    c->members.push_back(e);
+    c->tables_ready = false;
+    return VBNMF_OK;
+}
+
+// In-place all-reduce of the reduce buffer on the engine's stream: the exchange between step_local and step_finish
+// (and between set_state and state_finish) of a host-stepped partitioned run, from C (RCCL communicators).
+int vbnmf_engine_allreduce(vbnmf_engine *e)
+{
+    if (!e) return fail(VBNMF_ERR_BAD_ARG, "engine handle is NULL");
+    if (!e->comm || e->comm->kind != 0) return fail(VBNMF_ERR_STATE, "allreduce needs an RCCL communicator attached to the engine");
+    if (int rc = use_device(e)) return rc;
+    return rccl_check(rccl_api().AllReduce(e->red, e->red, (size_t)e->red_count, ncclDouble, ncclSum, e->comm->nc, e->stream), "ncclAllReduce");
+}
+
+static int group_members(vbnmf_comm *c, LoopGroup &G)
+{
+    if (!c) return fail(VBNMF_ERR_BAD_ARG, "communicator handle is NULL");
+    if (c->kind != 1) return fail(VBNMF_ERR_STATE, "not a local group (an RCCL communicator is driven through its engine)");
+    if ((int)c->members.size() != c->nranks) return fail(VBNMF_ERR_STATE, "the local group has %d of its %d partitions attached", (int)c->members.size(), c->nranks);
+    for (vbnmf_engine *q : c->members) if (!q) return fail(VBNMF_ERR_STATE, "a partition engine of the group has been destroyed");
+    G.e = c->members.data(); G.count = c->nranks; G.comm = c;
+    return VBNMF_OK;
+}
+
+// Local group: the state exchange after set_state on every member (sums the reduce buffers in place, partition
+// order), then state_finish on each.
+int vbnmf_group_state_finish(vbnmf_comm *c)
+{
+    LoopGroup G{};
+    if (int rc = group_members(c, G)) return rc;
+    if (int rc = use_device(G.e[0])) return rc;
+    if (int rc = group_tables(c)) return rc;
+    for (int p = 0; p < G.count; p++) {
+        if (!G.e[p]->prime_pending) return fail(VBNMF_ERR_STATE, "group_state_finish: partition %d has no pending set_state", p);
+        HIPCHECK(hipStreamSynchronize(G.e[p]->stream));
+    }
+    vbnmf_engine *L = G.e[0];
+    // in place: every element is read from all partitions before it is written to any
+    std::vector<double *> ptr(G.count);
+    for (int p = 0; p < G.count; p++) ptr[p] = G.e[p]->red;
+    double **d_ptr = nullptr;
+    if (int rc = dev_alloc(&d_ptr, (size_t)G.count)) return rc;
+    hipError_t he = hipMemcpy(d_ptr, ptr.data(), G.count * sizeof(void *), hipMemcpyHostToDevice);
+    if (he == hipSuccess) {
+        hipLaunchKernelGGL(k_group_sum, dim3((unsigned)((L->red_count + 255) / 256)), dim3(256), 0, L->stream, (const double *const *)d_ptr, d_ptr, G.count, L->red_count);
+        he = hipGetLastError();
+    }
+    if (he == hipSuccess) he = hipStreamSynchronize(L->stream);
+    (void)hipFree(d_ptr);
+    if (he != hipSuccess) return fail(VBNMF_ERR_HIP, "group state exchange failed: %s", hipGetErrorString(he));
+    for (int p = 0; p < G.count; p++)
+        if (int rc = vbnmf_engine_state_finish(G.e[p])) return rc;
+    return VBNMF_OK;
+}
+
+int vbnmf_group_run(vbnmf_comm *c, double *hyper, double fudge, int32_t max_it, double tol, int32_t n0, int32_t dn,
+                    const int32_t *flags, int32_t *it_out, double *lk0_out, double *lkh_out, int32_t *reason_out,
+                    double *history, int64_t history_rows)
+{
+    LoopGroup G{};
+    if (int rc = group_members(c, G)) return rc;
+    if (int rc = use_device(G.e[0])) return rc;
+    if (int rc = group_tables(c)) return rc;
+    return run_group(G, hyper, fudge, max_it, tol, n0, dn, flags, it_out, lk0_out, lkh_out, reason_out, history, history_rows);
 }
 
 int vbnmf_engine_get_state(vbnmf_engine *e, double *lw, double *lh, double *ew, double *eh, double *dw, double *dh)
@@ -965,62 +1382,51 @@ int vbnmf_engine_ml_run(vbnmf_engine *e, int32_t prior, double gamma_a, double g
     LoopCtl c{};
     c.lk0 = -INFINITY;                                             // lkold <- -Inf (:193)
     c.tol = tol; c.max_it = max_it;
-    double *d_hist = nullptr;
-    if (history) { if (int rc = dev_alloc(&d_hist, (size_t)max_it)) return rc; }
-    auto cleanup = [&](int rc) { e->run_active = false; (void)hipFree(d_hist); return rc; };
-    hipError_t he = hipMemcpyAsync(e->ctl, &c, sizeof c, hipMemcpyHostToDevice, e->stream);
-    if (he == hipSuccess) he = hipStreamSynchronize(e->stream);    // `c` is on this stack frame
-    if (he != hipSuccess) return cleanup(fail(VBNMF_ERR_HIP, "loading the loop control block failed: %s", hipGetErrorString(he)));
+    if (history) { if (int rc = ensure_history(e, (size_t)max_it)) return rc; }
+    hipLaunchKernelGGL(k_ctl_init, dim3(1), dim3(1), 0, e->stream, e->ctl, c);
+    hipError_t he = hipGetLastError();
+    if (he != hipSuccess) return fail(VBNMF_ERR_HIP, "loading the loop control block failed: %s", hipGetErrorString(he));
     volatile double *ho = e->h_out;
     ho[5] = 0.0; ho[6] = 0.0; ho[7] = 0.0;
     e->run_active = true;
     const bool timing = e->timing;
     e->timing = false;                                             // event pairs cannot follow launches queued ahead
-    auto done_with = [&](int rc) { e->timing = timing; return cleanup(rc); };
-
-    const int batch = 8;
-    int queued = 0;
-    bool stopped = false;
-    while (!stopped) {
-        const int done = (int)ho[7];
-        while (queued < max_it && queued - done < 2 * batch) {
-            int rc = launch_ml_update(e, false, prior, gamma_a, gamma_b, eps);
-            if (!rc) rc = launch_sweep1(e, true);
-            if (!rc) rc = launch_ml_update(e, true, prior, gamma_a, gamma_b, eps);
-            if (!rc) rc = launch_sweep1(e, false);
-            if (rc) return done_with(rc);
-            switch (e->R) {
-#define X(RR) case RR: hipLaunchKernelGGL((k_ml_control<RR>), dim3(1), dim3(1024), 0, e->stream, e->bpW, e->bpH, kUpdateBlocks, e->epart + e->n_wg, (int64_t)e->n_wg, e->xlx, e->r, (double)e->n, (double)e->m, e->ctl, d_hist, e->h_out_dev); break;
-                VBNMF_FOR_EACH_R(X)
+    e->ev_recorded = false; e->ev2_recorded = false;
+    auto done_with = [&](int rc) {
+        (void)hipStreamSynchronize(e->stream);
+        e->timing = timing; e->run_active = false;
+        e->seq = 0.0; e->h_out[7] = 0.0;                            // the step path's sequence flag restarts
+        return rc;
+    };
+    double *hist_dev = history ? e->h_hist_dev : nullptr;
+    int rc = drive_loop(e, max_it, [&]() -> int {
+        int q = launch_ml_update(e, false, prior, gamma_a, gamma_b, eps);
+        if (!q) q = launch_sweep1(e, true);
+        if (!q) q = launch_ml_update(e, true, prior, gamma_a, gamma_b, eps);
+        if (!q) q = launch_sweep1(e, false);
+        if (q) return q;
+        switch (e->R) {
+#define X(RR) case RR: hipLaunchKernelGGL((k_ml_control<RR>), dim3(1), dim3(1024), 0, e->stream, e->bpW, e->bpH, kUpdateBlocks, e->epart + e->n_wg, (int64_t)e->n_wg, e->xlx, e->r, (double)e->n, (double)e->m, e->ctl, hist_dev, e->h_out_dev); break;
+            VBNMF_FOR_EACH_R(X)
 #undef X
-                default: return done_with(fail(VBNMF_ERR_BAD_ARG, "unsupported padded rank %d", e->R));
-            }
-            if ((he = hipGetLastError()) != hipSuccess) return done_with(fail(VBNMF_ERR_HIP, "k_ml_control launch failed: %s", hipGetErrorString(he)));
-            queued++;
+            default: return fail(VBNMF_ERR_BAD_ARG, "unsupported padded rank %d", e->R);
         }
-        long spins = 0;
-        while (true) {
-            if (ho[6] != 0.0) { stopped = true; break; }
-            const int d2 = (int)ho[7];
-            if (d2 >= max_it) { stopped = true; break; }
-            if (queued < max_it && queued - d2 < 2 * batch) break;
-            if ((++spins & 0xFFFF) == 0) {
-                hipError_t q = hipStreamQuery(e->stream);
-                if (q != hipSuccess && q != hipErrorNotReady) return done_with(fail(VBNMF_ERR_HIP, "the loop failed on the device: %s", hipGetErrorString(q)));
-                if (q == hipSuccess && ho[6] == 0.0 && (int)ho[7] < queued) return done_with(fail(VBNMF_ERR_HIP, "the device went idle before the queued steps finished"));
-            }
-        }
-    }
+        hipError_t le = hipGetLastError();
+        if (le != hipSuccess) return fail(VBNMF_ERR_HIP, "k_ml_control launch failed: %s", hipGetErrorString(le));
+        return VBNMF_OK;
+    });
+    if (rc) return done_with(rc);
     he = hipStreamSynchronize(e->stream);
-    if (he == hipSuccess) he = hipMemcpy(&c, e->ctl, sizeof c, hipMemcpyDeviceToHost);
-    if (he == hipSuccess && history && c.it > 0) he = hipMemcpy(history, d_hist, (size_t)c.it * sizeof(double), hipMemcpyDeviceToHost);
-    if (he != hipSuccess) return done_with(fail(VBNMF_ERR_HIP, "reading the loop result failed: %s", hipGetErrorString(he)));
-    if (it_out) *it_out = c.it;
-    if (lk_out) *lk_out = c.lkh;
-    if (reason_out) *reason_out = c.reason;
-    e->h_out[0] = c.lkh;                                            // ml_likelihood() keeps answering for the pair held now
-    e->seq = 0.0; e->h_out[7] = 0.0;                                // the step path's sequence flag restarts
-    return done_with(VBNMF_OK);
+    if (he != hipSuccess) return done_with(fail(VBNMF_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(he)));
+    const int it = (int)e->h_out[5];
+    const double lk_last = e->h_out[0];
+    if (it_out) *it_out = it;
+    if (lk_out) *lk_out = lk_last;
+    if (reason_out) *reason_out = (int)e->h_out[6];
+    if (history && it > 0) std::memcpy(history, e->h_hist, (size_t)it * sizeof(double));
+    rc = done_with(VBNMF_OK);
+    e->h_out[0] = lk_last;                                          // ml_likelihood() keeps answering for the pair held now
+    return rc;
 }
 
 int vbnmf_engine_ml_get_state(vbnmf_engine *e, double *w, double *h)

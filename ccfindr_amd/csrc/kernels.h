@@ -94,9 +94,6 @@ constexpr uint32_t kLdsRowBase = kLdsCtrBase + 16;
 template <int R>
 __device__ __forceinline__ void lds_row(const double2 *__restrict__ ldsG, uint32_t byte_off, double2 (&gv)[R / 2])
 {
-#if defined(VBNMF_ABLATE_LDS_BCAST)
-    byte_off = 0;                                          // every lane reads row 0: pure broadcast, no conflicts
-#endif
     (void)ldsG;
     typedef double __attribute__((ext_vector_type(2))) Pair;
     typedef const __attribute__((address_space(3))) Pair LdsPair;
@@ -142,31 +139,32 @@ __device__ __forceinline__ void sweep_entry(SweepRegs<R> &S, const double2 *__re
         w1 = fma(S.F[2 * kk + 1], gv[kk].y, w1);
     }
     const double wth = w0 + w1;
-#if defined(VBNMF_ABLATE_NODIV)
-    const double q = x * wth;
-#else
     const double q = dev_div_fast(x, wth);
-#endif
 #pragma unroll
     for (int kk = 0; kk < R / 2; kk++) {
         S.acc[2 * kk] = fma(q, gv[kk].x, S.acc[2 * kk]);
         S.acc[2 * kk + 1] = fma(q, gv[kk].y, S.acc[2 * kk + 1]);
     }
-#if defined(VBNMF_ABLATE_NOLOG)
-    if (logterm) S.lsum = fma(x, wth, S.lsum);
-#else
     if (logterm) S.lsum = fma(x, dev_log_tab(wth, reinterpret_cast<const LogTabEntry *>(ldsG)), S.lsum);
-#endif
 }
 
-// Next slice ticket of the workgroup: lane 0 increments the LDS counter, every lane gets the value.
-// Kept out of line on purpose: inlined into the slice loop, hipcc (ROCm 7.2) merged the wave-uniform
-// exit test with its per-lane atomic rewrite into a loop nest that re-read a stale ticket and never ended.
-__device__ __attribute__((noinline)) int take_ticket(int *ticket)
+// Next slice ticket of the workgroup, wave-uniform by construction: EVERY lane adds 1 to the LDS counter (the
+// compiler folds the 64 adds into one ds_add_rtn of 64 by the first active lane), so there is no divergent branch
+// in the source, the old value is a multiple of 64 whichever lane's return is read, and the ticket old / 64 lives in
+// an SGPR: the slice loop's exit is a scalar compare-and-branch (s_cmp_ge_i32 / s_cbranch_scc1 in the ISA).
+// Why not "lane 0 adds, the others take i = 0, then __shfl / readfirstlane": inlined into the slice loop, hipcc
+// (ROCm 7.2) threads the back edge of the lanes that skip the atomic -- for which i = 0 is a compile-time constant --
+// straight to the exit test, i.e. it splits the loop into an outer one (lane 0: ds_add_rtn) and an inner one that the
+// other 63 lanes re-enter with v6 = 0 while lane 0 has left it; their ds_bpermute / v_readfirstlane then reads an
+// inactive (or the wrong first active) lane, gets ticket 0 < cn again and the wave never leaves slice 0.  (Seen in
+// the ISA of k_sweep<10, false, 768>: loop header `ds_bpermute_b32 v108, v98, v6`, latch `v_mov_b32 v6, 0` behind
+// an exec mask built from the lane == 0 predicate; the same nest appears with readfirstlane.)  LLVM's convergent
+// attribute does not pin which lanes meet at a cross-lane operation inside a loop, so the rewrite is not a bug it
+// acknowledges; round 1 hid it behind __attribute__((noinline)).  Without a divergent branch there is nothing to thread.
+__device__ __forceinline__ int take_ticket(int *ticket)
 {
-    int i = 0;
-    if ((threadIdx.x & 63) == 0) i = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    return __shfl(i, 0, 64);
+    const int old = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return __builtin_amdgcn_readfirstlane(old) >> 6;
 }
 
 // EV selects the per-slice scalar left in the evidence slots: 1 = the VB data term sum(acc . llF) - sum x log(wth)
@@ -348,12 +346,14 @@ __global__ __launch_bounds__(NT) void k_sweep(const SweepSide A, const SweepSide
 
 // One side alone (ML-NMF: its H and W updates are sequential, reference R/factorize.R:8-24, so each needs its
 // own pass over X; the cell-side pass also yields the likelihood's sum x log(wh)).
-template <int R, bool WIDE, bool LOGTERM, int NT>
+// VB = true: one side of the VB sweep launched alone, with the VB evidence partial (EV = 1): cell-partitioned engines
+// run the gene side first, so that its statistics can be all-reduced while the cell side runs.
+template <int R, bool WIDE, bool LOGTERM, int NT, bool VB = false>
 __global__ __launch_bounds__(NT) void k_sweep1(const SweepSide S)
 {
     extern __shared__ double2 ldsG[];
-    if (S.stop && *S.stop) return;               // device-driven ML loop: the run has ended
-    sweep_side<R, WIDE, LOGTERM, NT, LOGTERM ? 2 : 0>(S, ldsG);
+    if (S.stop && *S.stop) return;               // device-driven loop: the run has ended
+    sweep_side<R, WIDE, LOGTERM, NT, VB ? 1 : (LOGTERM ? 2 : 0)>(S, ldsG);
 }
 
 // Sparse product on the tiled layout (the truncated SVD behind the svd2 initialiser,
@@ -554,6 +554,29 @@ __global__ __launch_bounds__(256) void k_pack(const double *__restrict__ part, c
     out[e] = task_sum(part, inv_task, inv_ptr[M], inv_ptr[M + 1], R, k);
 }
 
+// Device-driven loop of a cell-partitioned engine: the reduce buffer is sent in two pieces.  The first,
+// [swsum n*R | rowSum(eh)_k (R) | sum H-terms | sum log lh], is complete once the gene-side sweep and the H update are
+// done (k_pack + k_tail_h) and travels while the cell-side sweep runs; the second, [data term | sum lgamma(x+1)], needs
+// both sweeps (k_tail_data) and is two doubles.
+__global__ __launch_bounds__(1024) void k_tail_h(const double *__restrict__ bpH, int nbH, int R, double *__restrict__ tail,
+                                                 const int32_t *__restrict__ stop)
+{
+    if (stop && *stop) return;
+    bp_colsums(bpH, nbH, R + 2, tail, 1024);
+}
+
+// In-process stand-in for the all-reduce between partition engines that share one device (tests, single-GPU
+// rehearsals of a partitioned run): recv[p][i] = send[0][i] + send[1][i] + ... in partition order, for every p.
+__global__ __launch_bounds__(256) void k_group_sum(const double *const *__restrict__ send, double *const *__restrict__ recv,
+                                                   int parts, int64_t count)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    double s = send[0][i];
+    for (int p = 1; p < parts; p++) s += send[p][i];
+    for (int p = 0; p < parts; p++) recv[p][i] = s;
+}
+
 // Sum of v[0..count) by one 1024-thread block: thread t adds t, t+1024, ... in order, then a tree.
 __device__ __forceinline__ double block_vec_sum(const double *__restrict__ v, int64_t count, double *sm)
 {
@@ -578,6 +601,15 @@ __global__ __launch_bounds__(1024) void k_tail(const double *__restrict__ bpH, i
     bp_colsums(bpH, nbH, R + 2, tail, 1024);
     const double data = block_vec_sum(epart, nepart, sm);
     if (threadIdx.x == 0) { tail[R + 2] = data; tail[R + 3] = lgx; }
+}
+
+__global__ __launch_bounds__(1024) void k_tail_data(const double *__restrict__ epart, int64_t nepart, double lgx,
+                                                    double *__restrict__ out2, const int32_t *__restrict__ stop)
+{
+    __shared__ double sm[1024];
+    if (stop && *stop) return;
+    const double data = block_vec_sum(epart, nepart, sm);
+    if (threadIdx.x == 0) { out2[0] = data; out2[1] = lgx; }
 }
 
 // Evidence and the four hyper statistics.  One block.
@@ -653,10 +685,20 @@ __device__ inline int dev_hyper_update_pair(const int32_t *flags, const double *
         int i = 1;
         while (i < 100) {                                                                  // Niter = 100 (:343)
             double d = fa ? (log(a0) - dev_digamma1(a0) - em / b0 + 1.0 + lm - log(b0)) / (1.0 / a0 - dev_trigamma(a0)) : 0.0;
+            // A non-finite step (a statistic of -inf: fudge = 0 with a shape so small that exp(psi) underflows to 0)
+            // would make the reference's halving loop below spin for ever -- on the host there, on the GPU here.
+            // It is reported as a failed hyper-parameter update (reason 3) instead; the halvings are bounded too
+            // (a finite d reaches a1 > 0 in < 1100 of them).
+            int bad = !(fabs(d) <= 1.79769313486231570815e308);
             a1 = a0 - d;
-            while (a1 <= 0.0) { d *= 0.5; a1 = a0 - d; }                                   // :28-35
-            const double u = 1.0 - a1 / a0;
+            for (int hv = 0; !bad && a1 <= 0.0; hv++) {                                    // :28-35
+                d *= 0.5; a1 = a0 - d;
+                if (hv >= 1100) bad = 1;
+            }
+            const double u = bad ? 0.0 : 1.0 - a1 / a0;
             const double uw = __shfl(u, 0, 64), uh = __shfl(u, 1, 64);
+            bad = __shfl(bad, 0, 64) | __shfl(bad, 1, 64);
+            if (bad) { failed = 1; break; }
             if (uw * uw + uh * uh < 1e-3) break;                                           // Tol = 1e-3 (:344)
             a0 = a1; i++;
         }
@@ -674,18 +716,28 @@ __device__ inline int dev_hyper_update_pair(const int32_t *flags, const double *
 //   it <- it+1 ; hyper_update if it > n0 and it %% dn == 0 (:342-344) ; break on NaN (:345) ;
 //   break if it > 1, it > n0, lkh >= lk0 and |1 - lkh/lk0| < Tol (:346-347, lk0 NOT refreshed) ; lk0 <- lkh (:348).
 // history row it-1 = [lkh, 4 statistics, 4 hyper-parameters after the update]; out_host = [lkh, 4 stats, it, reason, it].
+// Cell-partitioned engines hand in the all-reduced pieces instead: tail_in = [rowSum(eh)_k | sum H-terms | sum log lh]
+// (R + 2 doubles) and small_in = [data term | sum lgamma(x+1)], both summed over the partitions; bpW is replicated.
 template <int R>
 __global__ __launch_bounds__(1024) void k_control(const double *__restrict__ bpW, const double *__restrict__ bpH, int nb,
                                                   const double *__restrict__ epart, int64_t nepart, double lgx, int r,
                                                   double n, double m_global, LoopCtl *ctl, double *__restrict__ history,
-                                                  double *__restrict__ out_host)
+                                                  double *__restrict__ out_host, const double *__restrict__ tail_in,
+                                                  const double *__restrict__ small_in)
 {
     if (ctl->stop) return;
     __shared__ double sW[R + 2], sT[R + 4];
     __shared__ double sm[1024];
     bp_colsums(bpW, nb, R + 2, sW, 1024);
-    bp_colsums(bpH, nb, R + 2, sT, 1024);
-    const double data = block_vec_sum(epart, nepart, sm);
+    double data;
+    if (tail_in) {
+        if (threadIdx.x < R + 2) sT[threadIdx.x] = tail_in[threadIdx.x];
+        data = small_in[0]; lgx = small_in[1];
+        __syncthreads();
+    } else {
+        bp_colsums(bpH, nb, R + 2, sT, 1024);
+        data = block_vec_sum(epart, nepart, sm);
+    }
     const int lane = threadIdx.x;
     if (lane > 1) return;                        // lanes 0 and 1 go on (the two Newton recurrences of hyper_update)
     double cross = 0.0, sew = 0.0, seh = 0.0;
@@ -714,12 +766,16 @@ __global__ __launch_bounds__(1024) void k_control(const double *__restrict__ bpW
     }
     if (reason) { ctl->reason = reason; ctl->stop = 1; }
     out_host[0] = lkh;
-    for (int q = 0; q < 4; q++) out_host[1 + q] = st[q];
+    for (int q = 0; q < 4; q++) { out_host[1 + q] = st[q]; out_host[8 + q] = ctl->hyper[q]; }
+    out_host[12] = ctl->lk0;
     out_host[5] = (double)it;
     __threadfence_system();
     reinterpret_cast<volatile double *>(out_host)[6] = (double)reason;
     reinterpret_cast<volatile double *>(out_host)[7] = (double)it;
 }
+
+// Loads the control block of a device-driven loop (stream-ordered, no host copy to wait for).
+__global__ void k_ctl_init(LoopCtl *ctl, const LoopCtl v) { *ctl = v; }
 
 // Device-side evaluation of the special functions, for tests (tests/test_gpu_special.py).
 __global__ void k_test_special(int kind, int64_t n, const double *__restrict__ x, double *__restrict__ y,

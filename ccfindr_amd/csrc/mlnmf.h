@@ -118,6 +118,7 @@ __global__ __launch_bounds__(1024) void k_ml_control(const double *__restrict__ 
     if (history) history[it - 1] = lk;
     if (reason) { ctl->reason = reason; ctl->stop = 1; }
     out_host[0] = lk;
+    out_host[12] = ctl->lk0;
     out_host[5] = (double)it;
     __threadfence_system();
     reinterpret_cast<volatile double *>(out_host)[6] = (double)reason;

@@ -259,6 +259,15 @@ class VBEngine:
                 "hyper": dict(zip(("aw", "bw", "ah", "bh"), (float(v) for v in hy))),
                 "history": hist[:it.value] if history else None}
 
+    # -- communicators (cell-partitioned runs) -------------------------------------------------
+    def attach_comm(self, comm):
+        N.check(self._lib.vbnmf_engine_attach_comm(self._h, comm._h))
+        self.comm = comm
+
+    def allreduce(self):
+        """In-place RCCL all-reduce of the reduce buffer on the engine's stream (native communicator attached)."""
+        N.check(self._lib.vbnmf_engine_allreduce(self._h))
+
     def step_local(self, hyper, fudge=EPS):
         N.check(self._lib.vbnmf_engine_step_local(self._h, hyper["aw"], hyper["bw"], hyper["ah"], hyper["bh"], float(fudge)))
 
@@ -306,6 +315,72 @@ class VBEngine:
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
             self._lib.vbnmf_engine_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _run_outputs(Itmax, history):
+    return (ctypes.c_int32(), ctypes.c_int32(), ctypes.c_double(), ctypes.c_double(),
+            np.zeros((int(Itmax), 9)) if history else None)
+
+
+class Communicator:
+    """``vbnmf_comm``: the all-reduce of a cell-partitioned run, owned by the library.
+
+    ``Communicator.rccl(id, nranks, rank, device)`` -- one process per GPU; ``id`` comes from
+    ``Communicator.unique_id()`` on rank 0 and is broadcast by the caller.  ``Communicator.local(nranks, device)`` --
+    the partition engines share this process and one device (tests, single-GPU rehearsals)."""
+
+    def __init__(self, handle, kind, nranks, rank):
+        self._lib = N.load()
+        self._h = handle
+        self.kind, self.nranks, self.rank = kind, nranks, rank
+
+    @staticmethod
+    def unique_id():
+        buf = ctypes.create_string_buffer(N.COMM_ID_BYTES)
+        N.check(N.load().vbnmf_comm_unique_id(buf, N.COMM_ID_BYTES))
+        return buf.raw
+
+    @classmethod
+    def rccl(cls, uid, nranks, rank, device):
+        h = ctypes.c_void_p()
+        buf = ctypes.create_string_buffer(bytes(uid), N.COMM_ID_BYTES)
+        N.check(N.load().vbnmf_comm_create(buf, N.COMM_ID_BYTES, int(nranks), int(rank), int(device), ctypes.byref(h)))
+        return cls(h, "rccl", int(nranks), int(rank))
+
+    @classmethod
+    def local(cls, nranks, device=0):
+        h = ctypes.c_void_p()
+        N.check(N.load().vbnmf_comm_create_local(int(nranks), int(device), ctypes.byref(h)))
+        return cls(h, "local", int(nranks), 0)
+
+    # -- local groups: every member engine attached, in partition order ---------------------------------
+    def state_finish(self):
+        N.check(self._lib.vbnmf_group_state_finish(self._h))
+
+    def run(self, hyper, Itmax=10000, Tol=1e-5, n0=10, dn=1, flags=(True,) * 4, fudge=EPS, history=False):
+        """``VBEngine.run`` for the whole local group (same result dictionary)."""
+        hy = (ctypes.c_double * 4)(*(float(hyper[k]) for k in ("aw", "bw", "ah", "bh")))
+        fl = (ctypes.c_int32 * 4)(*(1 if f else 0 for f in flags))
+        it, reason, lk0, lkh, hist = _run_outputs(Itmax, history)
+        N.check(self._lib.vbnmf_group_run(self._h, hy, float(fudge), int(Itmax), float(Tol), int(n0), int(dn), fl,
+                                          ctypes.byref(it), ctypes.byref(lk0), ctypes.byref(lkh), ctypes.byref(reason),
+                                          N.dptr(hist), int(Itmax) if history else 0))
+        if reason.value == 3:
+            raise RuntimeError("Hyper-parameter update failed to converge")      # reference R/bayesian.R:43
+        return {"it": it.value, "lk0": lk0.value, "lkh": lkh.value, "reason": reason.value,
+                "hyper": dict(zip(("aw", "bw", "ah", "bh"), (float(v) for v in hy))),
+                "history": hist[:it.value] if history else None}
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.vbnmf_comm_destroy(self._h)
             self._h = ctypes.c_void_p()
 
     def __del__(self):

@@ -26,6 +26,10 @@ from .engine import EPS, VBEngine
 # ---------------------------------------------------------------------------------------
 # rank sweep / restarts
 # ---------------------------------------------------------------------------------------
+class ShardedRunError(RuntimeError):
+    """A (run, rank) unit of a sharded sweep failed on some process; raised on EVERY process."""
+
+
 def lpt_schedule(costs, n_workers):
     """Longest-processing-time-first assignment.  Returns ``n_workers`` lists of task indices;
     ties go to the lowest worker id, so every process computes the same schedule."""
@@ -69,18 +73,34 @@ def vb_factorize_sharded(mat, ranks=2, nrun=1, verbose=0, initializer="random", 
     tasks, costs = sweep_tasks(bundle["ranks"], nrun)
     mine = lpt_schedule(costs, world)[me]
     bundle["engines"] = {} if nrun > 1 else None        # this process's restarts of a rank share the engine
+    # A unit that raises (hyper-parameter Newton failure, a VBNMFError, rank > min(nrow, ncol) ...) must not keep
+    # this process from the gather below: the other processes would wait in it for ever.  The error travels as a
+    # record, every process reaches the collective, and then every process raises the first error (by unit order).
+    local, failure = {}, None
     try:
-        local = {tasks[t]: vb_run_rank(tasks[t][0], tasks[t][1], bundle) for t in mine}
+        for t in mine:
+            try:
+                local[tasks[t]] = vb_run_rank(tasks[t][0], tasks[t][1], bundle)
+            except Exception as exc:                                 # noqa: BLE001 -- re-raised after the gather
+                failure = (t, me, type(exc).__name__, str(exc))
+                break
     finally:
         _close_engines(bundle)
     if world > 1:
         gathered = [None] * world
-        dist.all_gather_object(gathered, local, group=group)        # control plane: host objects, once per sweep
+        dist.all_gather_object(gathered, (local, failure), group=group)   # control plane: host objects, once per sweep
         records = {}
-        for part in gathered:
+        failures = []
+        for part, fail in gathered:
             records.update(part)
+            if fail is not None:
+                failures.append(fail)
     else:
-        records = local
+        records, failures = local, ([failure] if failure is not None else [])
+    if failures:
+        t, who, kind, msg = min(failures)
+        irun, r = tasks[t]
+        raise ShardedRunError(f"unit (run {irun}, rank {r}) failed on process {who}: {kind}: {msg}")
     vb = []
     for irun in range(1, nrun + 1):
         per_rank = {r: records[(irun, r)] for r in bundle["ranks"] if (irun, r) in records}
@@ -99,31 +119,55 @@ def cell_partition(m, world):
 class CellPartitionedEngine:
     """One factorisation over all GPUs of a process group, cells partitioned.
 
-    Same surface as ``VBEngine`` (``set_state``, ``step``, ``get_state``); ``lh``/``eh`` arguments
+    Same surface as ``VBEngine`` (``set_state``, ``step``, ``run``, ``get_state``); ``lh``/``eh`` arguments
     and results are FULL r x m matrices, each process uses / returns its own column block
-    (``get_state`` all-gathers the blocks).  ``engine`` injects the per-partition engine (the CPU
-    tests drive this class over gloo with a numpy engine); by default it is a HIP ``VBEngine``
-    created on ``device`` for this process's block.
+    (``get_state`` all-gathers the blocks).
+
+    The per-step all-reduce is the LIBRARY's (``native=True``, the default on an RCCL process group or without one):
+    rank 0 draws an RCCL id, ``torch.distributed`` broadcasts it once (control plane), every process builds a
+    ``vbnmf_comm`` and attaches it to its partition engine; ``step`` is then step_local / vbnmf_engine_allreduce /
+    step_finish and ``run`` the device-driven loop of vbnmf_engine_run, with no Python and no torch between steps.
+    ``native=False`` keeps the exchange in ``torch.distributed`` on the engine's stream (gloo rehearsals of the
+    multi-process path on one GPU -- RCCL refuses two ranks on a device -- and the CPU tests, which inject a numpy
+    engine through ``engine``); there is no device-driven loop on that path.
     """
 
-    def __init__(self, X, rank, device=0, group=None, engine=None):
+    def __init__(self, X, rank, device=0, group=None, engine=None, native=None):
         import torch
         import torch.distributed as dist
         self._torch, self._dist = torch, dist
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.me = dist.get_rank(group) if dist.is_initialized() else 0
+        inited = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if inited else 1
+        self.me = dist.get_rank(group) if inited else 0
         n, m = X.shape
         self.n, self.m_global, self.rank = n, m, int(rank)
         self.cols = cell_partition(m, self.world)[self.me]
         self.m = self.cols[1] - self.cols[0]
+        injected = engine is not None
         if engine is None:
             engine = VBEngine(X, rank, device=device, cols=self.cols, m_global=m)
         self.engine = engine
-        self._red = engine.reduce_tensor()
+        if native is None:
+            native = (not injected) and (not inited or dist.get_backend(group) == "nccl")
+        self.native = bool(native)
+        self.comm = None
+        if self.native:
+            from .engine import Communicator
+            box = [Communicator.unique_id() if self.me == 0 else None]
+            if self.world > 1:
+                dist.broadcast_object_list(box, src=0, group=group)          # control plane, once per engine
+            self.comm = Communicator.rccl(box[0], self.world, self.me, device)
+            engine.attach_comm(self.comm)
+            self._red = None
+        else:
+            self._red = engine.reduce_tensor()
         self._stream_ctx = getattr(engine, "stream_context", None)
 
     def _allreduce(self):
+        if self.native:
+            self.engine.allreduce()
+            return
         if self.world == 1:
             return
         red = self._red
@@ -145,7 +189,7 @@ class CellPartitionedEngine:
     def set_state(self, lw, lh, eh):
         cb, ce = self.cols
         self.engine.set_state(lw, np.asarray(lh)[:, cb:ce], np.asarray(eh)[:, cb:ce])
-        if self.world > 1:                      # an unpartitioned engine finishes set_state by itself
+        if self.world > 1 or self.native and self.m != self.m_global:   # an unpartitioned engine finishes set_state by itself
             self._allreduce()
             self.engine.state_finish()
 
@@ -154,6 +198,26 @@ class CellPartitionedEngine:
         self._allreduce()
         return self.engine.step_finish()
 
+    def run(self, hyper, **kw):
+        """The device-driven loop of ``VBEngine.run`` across the partitions (native communicator only): every
+        process calls it with the same arguments and gets the same result."""
+        if not self.native:
+            raise RuntimeError("the device-driven loop of a partitioned run needs the native (RCCL) communicator")
+        return self.engine.run(hyper, **kw)
+
+    def _gather_cells(self, a):
+        """r x m_local blocks -> the full r x m matrix on every process (one tensor all_gather, blocks padded to the
+        widest partition; no pickling)."""
+        torch, dist = self._torch, self._dist
+        counts = [e - b for b, e in cell_partition(self.m_global, self.world)]
+        on_gpu = dist.get_backend(self.group) == "nccl"
+        dev = torch.device("cuda", self.engine.device) if on_gpu else torch.device("cpu")
+        mine = torch.zeros((max(counts), a.shape[0]), dtype=torch.float64, device=dev)
+        mine[:a.shape[1]] = torch.from_numpy(np.ascontiguousarray(a.T)).to(dev)
+        parts = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(parts, mine, group=self.group)
+        return np.concatenate([p[:c].cpu().numpy().T for p, c in zip(parts, counts)], axis=1)
+
     def get_state(self, names=("lw", "lh", "ew", "eh", "dw", "dh")):
         local = self.engine.get_state(names)
         if self.world == 1:
@@ -161,13 +225,13 @@ class CellPartitionedEngine:
         out = {k: v for k, v in local.items() if k in ("lw", "ew", "dw")}
         for k in ("lh", "eh", "dh"):
             if k in local:
-                parts = [None] * self.world
-                self._dist.all_gather_object(parts, local[k], group=self.group)
-                out[k] = np.concatenate(parts, axis=1)
+                out[k] = self._gather_cells(local[k])
         return out
 
     def close(self):
         self.engine.close()
+        if self.comm is not None:
+            self.comm.close()
 
 
 def _hip_stream_context(engine):

@@ -151,10 +151,60 @@ int vbnmf_engine_state_finish(vbnmf_engine *e);
  * lk0, lkh of the last step, reason (1 NaN, 2 converged, 3 hyper Newton did not converge -- the
  * reference stops with an error there, :43 -- 4 max_it reached), history[it][9] = lkh, mean log lw,
  * mean log lh, mean ew, mean eh, then aw, bw, ah, bh after that step's update (history_rows >= max_it).
- * Unpartitioned engines only. */
+ * A partitioned engine needs an RCCL communicator attached (below); every process then calls this with the
+ * same arguments and gets the same results. */
 int vbnmf_engine_run(vbnmf_engine *e, double *hyper, double fudge, int32_t max_it, double tol, int32_t n0,
                      int32_t dn, const int32_t *flags, int32_t *it, double *lk0, double *lkh, int32_t *reason,
                      double *history, int64_t history_rows);
+
+/* ---------------------------------------------------------------------------------
+ * Communicators for cell-partitioned runs.  The reference has no counterpart inside
+ * an iteration: its only inter-process mechanism is Rmpi::mpi.applyLB over restarts (R/bayesian.R:262-263),
+ * and vb_iterate's loop (R/bayesian.R:337-352) runs in one process.  Here one factorisation can span the GPUs
+ * of a node, cells partitioned, one process per GPU, and the per-step exchange -- the sum over partitions of
+ * [sw (n x r) | rowSums(eh) (r) | 4 scalars] -- is an RCCL all-reduce over xGMI enqueued by the LIBRARY on
+ * the engine's streams, so a binding needs no collective of its own:
+ *
+ *   rank 0:   vbnmf_comm_unique_id(id)           then broadcast `id` (VBNMF_COMM_ID_BYTES) to every process
+ *                                                 by whatever the host language has (Rmpi::mpi.bcast, MPI_Bcast,
+ *                                                 torch.distributed.broadcast ...)
+ *   all:      vbnmf_comm_create(id, ..., nranks, rank, device, &comm)        ncclCommInitRank
+ *             vbnmf_engine_create_part(X, cb, ce, m, r, device, &e) ; vbnmf_engine_attach_comm(e, comm)
+ *             vbnmf_engine_set_state(e, ...) ; vbnmf_engine_allreduce(e) ; vbnmf_engine_state_finish(e)
+ *             vbnmf_engine_run(e, ...)           the whole loop of vb_iterate, device-driven, on every process;
+ *                                                 per step the n x r piece of the all-reduce travels beside the
+ *                                                 cell-side half of the sweep, every process takes the same
+ *                                                 (replicated) stop decision and queues the same collectives
+ *        or   vbnmf_engine_step_local(e, ...) ; vbnmf_engine_allreduce(e) ; vbnmf_engine_step_finish(e, ...)
+ *
+ * librccl is opened at run time (dlopen "librccl.so.1"); without it vbnmf_comm_create fails with
+ * VBNMF_ERR_NO_DEVICE and everything else keeps working.
+ *
+ * A LOCAL GROUP is the same protocol for partition engines that share ONE process and ONE device (RCCL
+ * refuses two ranks on a device): tests and single-GPU rehearsals of a partitioned run.  The engines are
+ * attached in partition order and driven together through vbnmf_group_state_finish / vbnmf_group_run; the
+ * all-reduce is a kernel that adds the partitions' buffers in partition order.
+ * --------------------------------------------------------------------------------- */
+typedef struct vbnmf_comm vbnmf_comm;
+#define VBNMF_COMM_ID_BYTES 128
+int vbnmf_comm_unique_id(void *id, int64_t bytes);
+int vbnmf_comm_create(const void *id, int64_t bytes, int32_t nranks, int32_t rank, int32_t device,
+                      vbnmf_comm **out);
+int vbnmf_comm_create_local(int32_t nranks, int32_t device, vbnmf_comm **out);
+/* nranks, this process's rank (0 for a local group), kind (0 RCCL, 1 local group); any pointer may be NULL. */
+int vbnmf_comm_info(const vbnmf_comm *c, int32_t *nranks, int32_t *rank, int32_t *kind);
+void vbnmf_comm_destroy(vbnmf_comm *c);
+/* The engine must live on the communicator's device.  An RCCL communicator takes one engine; a local group
+ * takes its nranks partition engines, in partition order. */
+int vbnmf_engine_attach_comm(vbnmf_engine *e, vbnmf_comm *c);
+/* In-place all-reduce (sum, fp64) of the engine's reduce buffer on the engine's stream (RCCL communicators). */
+int vbnmf_engine_allreduce(vbnmf_engine *e);
+/* Local groups: the state exchange after set_state on every member, and the device-driven loop of the whole
+ * group (arguments and results as vbnmf_engine_run; history comes from partition 0 -- all are identical). */
+int vbnmf_group_state_finish(vbnmf_comm *c);
+int vbnmf_group_run(vbnmf_comm *c, double *hyper, double fudge, int32_t max_it, double tol, int32_t n0,
+                    int32_t dn, const int32_t *flags, int32_t *it, double *lk0, double *lkh, int32_t *reason,
+                    double *history, int64_t history_rows);
 
 /* Download the current wh members (any pointer may be NULL):
  * lw, ew, dw : n x r ; lh, eh, dh : r x m_local.  dw, dh are variances, as the reference

@@ -82,3 +82,44 @@ def test_cell_partition_and_sharded_sweep_world2():
         assert measure["lml"] == serial.measure["lml"]        # same units, same seeds: bit-identical
         for a, b in zip(basis, serial.basis):
             assert np.array_equal(a, b)
+
+
+def _failing_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fake_engine import NumpyPhaseEngine
+        from ccfindr_amd import parallel
+        X = _data()
+
+        class Failing(NumpyPhaseEngine):
+            def step(self, hyper, fudge=None):
+                raise RuntimeError("Hyper-parameter update failed to converge")
+
+        # LPT order over ranks [4, 3, 2] on two processes: process 0 takes rank 4, process 1 ranks 3 and 2;
+        # the stand-in engine of rank 3 fails, so only process 1 sees the error directly
+        factory = lambda M, rk: (Failing if rk == 3 else NumpyPhaseEngine)(X, rk)
+        try:
+            parallel.vb_factorize_sharded(X, ranks=[2, 3, 4], nrun=1, Itmax=5, seed=11, engine_factory=factory)
+            q.put((rank, "no error"))
+        except parallel.ShardedRunError as exc:
+            q.put((rank, str(exc)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_sweep_unit_failure_reaches_every_rank():
+    """A unit that raises on ONE process must not leave the others waiting in the gather: every process raises."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31600 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_failing_worker, args=(k, 2, port, q)) for k in range(2)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=120) for _ in procs], key=lambda o: o[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert outs[0][1] == outs[1][1]
+    assert "rank 3" in outs[0][1] and "failed to converge" in outs[0][1] and "process 1" in outs[0][1]

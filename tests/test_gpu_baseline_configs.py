@@ -1,4 +1,4 @@
-"""GPU parity at the sizes BASELINE.json names (configs 2 and 3), plus size-independent properties.
+"""GPU parity at the sizes BASELINE.json names (configs 2, 3, 4 and 5), plus size-independent properties.
 
 The oracle's stored-entries form finishes one step of the 20k x 50k matrix in about a second, so the
 headline workload is checked directly against it, not only through invariants.
@@ -116,3 +116,127 @@ def test_rank_sweep_ranks_on_a_mid_size_matrix(r):
     for k in FACT:
         assert relerr(got[k], want[k]) <= 1e-12, (k, relerr(got[k], want[k]))
     assert abs(got["lkh"] / want["lkh"] - 1) <= 1e-10
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE config 4: ranks 2..20 on the 20k x 50k matrix, one (run, rank) unit per GPU (reference rank loop:
+# R/bayesian.R:316; the units are independent, R/bayesian.R:261-263).
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def c3_matrix(c3):
+    import ccfindr_amd as C
+    X, _ = c3
+    M = C.CountMatrix(X)
+    yield X, M
+    M.close()
+
+
+@pytest.mark.parametrize("r", [2, 5, 11, 15, 20])
+def test_config4_ranks_on_the_headline_matrix_against_sparse_oracle(c3_matrix, r):
+    """One resident step per rank on the full C3 matrix vs the oracle's stored-entries form.  The ranks cover every
+    geometry of the sweep kernel C4 uses: 1024 / 768 / 512 threads per workgroup (4 / 3 / 2 waves per SIMD), odd ranks
+    (padded column), and each LDS row size class."""
+    import ccfindr_amd as C
+    from ccfindr_amd import synth
+    from oracle import vbnmf_oracle as O
+    X, M = c3_matrix
+    n, m = X.shape
+    wh = synth.random_state(n, m, r, HY1, seed=1000 + r)
+    eng = C.VBEngine(M, r)
+    eng.set_state(wh["lw"], wh["lh"], wh["eh"])
+    lkh, stats = eng.step(HY1)
+    got = eng.get_state()
+    eng.close()
+    want = O.update_csc(n, m, X.indptr, X.indices, X.data, wh, HY1, nthreads=16)
+    assert abs(lkh / want["lkh"] - 1) <= 1e-10, (lkh, want["lkh"])
+    for k in FACT:
+        assert relerr(got[k], want[k]) <= 1e-11, (k, relerr(got[k], want[k]))
+    assert np.allclose(stats, (np.mean(np.log(want["lw"])), np.mean(np.log(want["lh"])), np.mean(want["ew"]), np.mean(want["eh"])), rtol=1e-10)
+
+
+def _c4_worker(rank, world, port, path, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    import scipy.sparse as sp
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ccfindr_amd import parallel
+        z = np.load(path, mmap_mode="r")
+        X = sp.csc_matrix((np.asarray(z["data"]), np.asarray(z["indices"]), np.asarray(z["indptr"])), shape=tuple(z["shape"]))
+        res = parallel.vb_factorize_sharded(X, ranks=[4, 10, 17], nrun=1, Itmax=12, seed=11, device=0)
+        q.put((rank, res.ranks, res.measure, res.nsteps, [np.asarray(b).copy() for b in res.basis]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_config4_sharded_sweep_two_processes_on_the_headline_matrix(c3, tmp_path):
+    """vb_factorize_sharded (LPT over the units, no data-path collective) across two processes on the C3 matrix, ranks
+    4 / 10 / 17, 12 iterations each: every process must return what the single-process vb_factorize returns, bit for bit.
+    (Both processes share the one test GPU; on the 8-GPU node each has its own.)"""
+    import torch.multiprocessing as mp
+    import ccfindr_amd as C
+    X, _ = c3
+    path = str(tmp_path / "c3.npz")
+    np.savez(path, data=X.data, indices=X.indices, indptr=X.indptr, shape=np.asarray(X.shape))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 30700 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_c4_worker, args=(k, 2, port, path, q)) for k in range(2)]
+    for p in procs:
+        p.start()
+    single = C.vb_factorize(X, ranks=[4, 10, 17], nrun=1, Itmax=12, seed=11, verbose=0)
+    outs = sorted([q.get(timeout=600) for _ in procs], key=lambda o: o[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert all(np.isfinite(v) for v in single.measure["lml"])
+    for _, ranks, measure, nsteps, basis in outs:
+        assert ranks == single.ranks and nsteps == single.nsteps and measure == single.measure
+        for a, b in zip(basis, single.basis):
+            assert np.array_equal(a, b)
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE config 5: 30 000 genes x 200 000 cells (~5 % stored), rank 20, cells partitioned 8 ways, one all-reduce of
+# [sw | rowSums(eh) | scalars] per step (SURVEY.md section 8e).  One test GPU: the eight partition engines live side by
+# side on it as a local group, whose in-process sum stands where the 8-GPU run has its RCCL all-reduce; everything
+# else -- partition layouts, the split sweep, k_pack, the replicated W update, the device-driven loop -- is the same code.
+# ------------------------------------------------------------------------------------------------
+def test_config5_30k_x_200k_rank20_eight_cell_partitions_against_sparse_oracle():
+    import ccfindr_amd as C
+    from ccfindr_amd import synth
+    from ccfindr_amd.parallel import cell_partition
+    from oracle import vbnmf_oracle as O
+    n, m, r, P, k = 30000, 200000, 20, 8, 20
+    depth = np.round(np.random.default_rng(5).lognormal(np.log(1950.0), 0.3, size=m)).astype(np.int64)
+    X = synth.fill_empty(synth.simulate_data(n, [m // k] * k, alpha0=0.1, seed=5, depth=depth), seed=5)
+    assert X.shape == (n, m) and 0.047 < X.nnz / (n * m) < 0.053
+    M = C.CountMatrix(X)
+    wh = synth.random_state(n, m, r, HY1, seed=1005)
+    cuts = cell_partition(m, P)
+    comm = C.Communicator.local(P)
+    parts = [C.VBEngine(M, r, cols=c, m_global=m) for c in cuts]
+    for p, (b, e) in zip(parts, cuts):
+        p.attach_comm(comm)
+        p.set_state(wh["lw"], wh["lh"][:, b:e], wh["eh"][:, b:e])
+    comm.state_finish()
+    steps = 2
+    res = comm.run(HY1, Itmax=steps, Tol=0.0, flags=(False,) * 4, history=True)
+    assert res["it"] == steps
+    S = X.tocsc()
+    ref = wh
+    for t in range(steps):
+        ref = O.update_csc(n, m, S.indptr, S.indices, S.data, ref, HY1, nthreads=16)
+        assert abs(res["history"][t, 0] / ref["lkh"] - 1) <= 1e-10, (t, res["history"][t, 0], ref["lkh"])
+    st = [p.get_state() for p in parts]
+    for key in ("lw", "ew", "dw"):
+        for q in st[1:]:
+            assert np.array_equal(st[0][key], q[key]), key           # replicated gene-side state: bit-identical
+        assert relerr(st[0][key], ref[key]) <= 1e-10, key
+    for key in ("lh", "eh", "dh"):
+        assert relerr(np.concatenate([q[key] for q in st], axis=1), ref[key]) <= 1e-10, key
+    for e in parts:
+        e.close()
+    comm.close()
+    M.close()

@@ -63,8 +63,8 @@ def test_two_partitions_equal_whole(n, m, r, cut):
 
 
 def test_cell_partitioned_engine_over_rccl_world1():
-    """CellPartitionedEngine with a real (1-rank) RCCL group: the all-reduce runs on the engine's
-    HIP stream through torch's ExternalStream, between step_local and step_finish."""
+    """CellPartitionedEngine with a real (1-rank) RCCL group, both exchange paths: torch.distributed's all-reduce on the
+    engine's HIP stream through ExternalStream (native=False), and the library's own ncclAllReduce (native=True)."""
     import os
     import torch
     import torch.distributed as dist
@@ -79,8 +79,11 @@ def test_cell_partitioned_engine_over_rccl_world1():
         X[0, :] += 1
         M = C.CountMatrix(X)
         wh = synth.random_state(90, 140, 3, HY, seed=4)
-        eng = parallel.CellPartitionedEngine(M, 3, device=0)
+        eng = parallel.CellPartitionedEngine(M, 3, device=0, native=False)
         eng.set_state(wh["lw"], wh["lh"], wh["eh"])
+        nat = parallel.CellPartitionedEngine(M, 3, device=0)
+        assert nat.native and nat.comm.kind == "rccl"
+        nat.set_state(wh["lw"], wh["lh"], wh["eh"])
         ref = C.VBEngine(M, 3)
         ref.set_state(wh["lw"], wh["lh"], wh["eh"])
         for _ in range(4):
@@ -89,7 +92,9 @@ def test_cell_partitioned_engine_over_rccl_world1():
             with eng.engine.stream_context():
                 dist.all_reduce(eng._red)
             got = eng.engine.step_finish()
-            assert got == ref.step(HY)
-        eng.close(); ref.close()
+            want = ref.step(HY)
+            assert got == want
+            assert nat.step(HY) == want                               # step_local / vbnmf_engine_allreduce / step_finish
+        eng.close(); nat.close(); ref.close()
     finally:
         dist.destroy_process_group()
