@@ -87,6 +87,7 @@ struct Layout {
     std::vector<int32_t> slice_width;    // n_slices ; entries per lane, multiple of 4
     std::vector<int64_t> slice_off;      // n_slices ; first slot of the slice
     std::vector<int32_t> slice_block;    // n_slices ; minor block (host-side bookkeeping / tests)
+    std::vector<int32_t> slice_fast;     // n_slices ; leading entries per lane that are stored ones in EVERY lane (multiple of 8)
     std::vector<int32_t> seg_block;      // n_segs
     std::vector<int32_t> wg_seg0;        // n_wg + 1
     std::vector<int32_t> seg_ptr;        // n_segs + 1 : first slice of each segment

@@ -436,7 +436,13 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
 
     lap("bpos");
     // tasks per block: (major, block) runs longer than max_len are cut in near-equal pieces
-    struct Task { uint32_t major; int32_t len; int64_t pos; };
+    // n1 = the task's entries of value exactly 1: they are placed first in the task, so that the sweep can run the
+    // leading trips of a slice -- as far as EVERY lane still sits on such entries -- through a shorter loop (no
+    // count conversion, and on the gene side a running product in place of a logarithm per entry, kernels.h).
+    // Tasks are therefore grouped by padded length first and, within a length class, by n1: the 64 tasks of a slice
+    // then agree on how long that leading stretch is.
+    struct Task { uint32_t major; int32_t len; int64_t pos; int32_t n1; };
+    const bool fast_ones = !L.wide && env_int("VBNMF_NO_FAST_ONES", 0) == 0;
     std::vector<std::vector<Task>> btasks(nblk);
     parallel_for(nblk, [&](int64_t b0, int64_t b1, int) {
         for (int64_t blk = b0; blk < b1; blk++) {
@@ -448,10 +454,17 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
                 int64_t pieces = (cnt + lp.max_len - 1) / lp.max_len;
                 for (int64_t pc = 0; pc < pieces; pc++) {
                     int64_t s = cnt * pc / pieces, t = cnt * (pc + 1) / pieces;
-                    T.push_back({(uint32_t)M, (int32_t)(t - s), q0 + s});
+                    int32_t n1 = 0;
+                    if (fast_ones) for (int64_t q = q0 + s; q < q0 + t; q++) n1 += (val[q] == 1.0);
+                    T.push_back({(uint32_t)M, (int32_t)(t - s), q0 + s, n1});
                 }
             }
-            std::stable_sort(T.begin(), T.end(), [](const Task &a, const Task &c2) { return a.len > c2.len; });
+            auto padded = [](int32_t len) { return (len + kWidthQuantum - 1) / kWidthQuantum; };
+            std::stable_sort(T.begin(), T.end(), [&](const Task &a, const Task &c2) {
+                const int32_t pa = padded(a.len), pc2 = padded(c2.len);
+                if (pa != pc2) return pa > pc2;
+                return a.n1 > c2.n1;
+            });
         }
     });
 
@@ -468,18 +481,23 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
     L.slice_block.assign(L.n_slices, 0);
     std::vector<int64_t> task_pos((size_t)L.n_slices * kLanes, 0);
     std::vector<int32_t> task_len((size_t)L.n_slices * kLanes, 0);
+    std::vector<int32_t> task_n1((size_t)L.n_slices * kLanes, 0);
+    L.slice_fast.assign(L.n_slices, 0);
     L.n_tasks = 0;
     for (int32_t blk = 0; blk < nblk; blk++) {
         const std::vector<Task> &T = btasks[blk];
         L.n_tasks += (int64_t)T.size();
         for (size_t q = 0; q < T.size(); q++) {
             size_t id = (size_t)bslice0[blk] * kLanes + q;
-            L.task_major[id] = T[q].major; task_pos[id] = T[q].pos; task_len[id] = T[q].len;
+            L.task_major[id] = T[q].major; task_pos[id] = T[q].pos; task_len[id] = T[q].len; task_n1[id] = T[q].n1;
         }
         for (int64_t s = bslice0[blk]; s < bslice0[blk + 1]; s++) {
-            int32_t w = task_len[(size_t)s * kLanes];            // sorted: first lane is the longest
+            int32_t w = task_len[(size_t)s * kLanes];            // sorted by padded length: the first lane's is the largest
             L.slice_width[s] = (w + kWidthQuantum - 1) / kWidthQuantum * kWidthQuantum;
             L.slice_block[s] = blk;
+            int32_t f = INT32_MAX;                               // leading entries that are ones in EVERY lane (idle lanes: none)
+            for (int l = 0; l < kLanes; l++) f = std::min(f, task_n1[(size_t)s * kLanes + l]);
+            L.slice_fast[s] = f / kWidthQuantum * kWidthQuantum;  // whole loop trips
         }
     }
     btasks.clear();
@@ -527,7 +545,10 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
     // time (see below).  With more blocks than workgroups, whole blocks are bin-packed onto workgroups instead.
     {
         const double c0 = 10.0;                              // per-slice overhead in entry-equivalents
-        auto cost = [&](int64_t s) { return (double)L.slice_width[s] + c0; };
+        // an entry of the leading stretch of ones costs the gene side (which carries the logarithm) ~0.6 and the cell
+        // side ~0.9 of an ordinary entry (instruction counts of the two loops, kernels.h)
+        const double fast_discount = side == 0 ? 0.4 : 0.1;
+        auto cost = [&](int64_t s) { return (double)L.slice_width[s] - fast_discount * (double)L.slice_fast[s] + c0; };
         std::vector<double> bcost(nblk, 0.0);
         double total = 0.0;
         for (int32_t blk = 0; blk < nblk; blk++) {
@@ -613,19 +634,21 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
         // Renumber the slices in processing order, so that list position == slice id: the kernel then finds
         // a slice's width, offset, majors and partial rows directly from its ticket, with no indirection.
         const std::vector<int32_t> &ord = order;
-        std::vector<int32_t> w2(L.n_slices), b2(L.n_slices), len2((size_t)L.n_slices * kLanes);
+        std::vector<int32_t> w2(L.n_slices), b2(L.n_slices), f2(L.n_slices), len2((size_t)L.n_slices * kLanes), n12((size_t)L.n_slices * kLanes);
         std::vector<uint32_t> maj2((size_t)L.n_slices * kLanes);
         std::vector<int64_t> pos2((size_t)L.n_slices * kLanes);
         for (int64_t s = 0; s < L.n_slices; s++) {
             const int64_t o = ord[s];
-            w2[s] = L.slice_width[o]; b2[s] = L.slice_block[o];
+            w2[s] = L.slice_width[o]; b2[s] = L.slice_block[o]; f2[s] = L.slice_fast[o];
             for (int l = 0; l < kLanes; l++) {
                 maj2[(size_t)s * kLanes + l] = L.task_major[(size_t)o * kLanes + l];
                 pos2[(size_t)s * kLanes + l] = task_pos[(size_t)o * kLanes + l];
                 len2[(size_t)s * kLanes + l] = task_len[(size_t)o * kLanes + l];
+                n12[(size_t)s * kLanes + l] = task_n1[(size_t)o * kLanes + l];
             }
         }
-        L.slice_width.swap(w2); L.slice_block.swap(b2); L.task_major.swap(maj2); task_pos.swap(pos2); task_len.swap(len2);
+        L.slice_width.swap(w2); L.slice_block.swap(b2); L.slice_fast.swap(f2); L.task_major.swap(maj2); task_pos.swap(pos2); task_len.swap(len2);
+        task_n1.swap(n12);
         int64_t o2 = 0;
         for (int64_t s = 0; s < L.n_slices; s++) { L.slice_off[s] = o2; o2 += (int64_t)L.slice_width[s] * kLanes; }
     }
@@ -656,8 +679,9 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
                                      2,2,2,2,3,3,3,3,3,3,3,3,2,2,2,2,3,3,3,3,2,2,2,2,2,2,2,2,3,3,3,3};
     const bool schedule = env_int("VBNMF_NO_BANK_SCHEDULE", 0) == 0;
     parallel_for(L.n_slices, [&](int64_t b, int64_t e, int) {
-        std::vector<int64_t> order;                       // entry positions of one lane in step order
-        std::vector<int32_t> bucket[16][16];              // [lane in group][residue] -> stack of positions
+        // [phase][lane in group][residue] -> stack of positions; phase 0 = the task's entries of value 1 (placed
+        // first, see above), phase 1 = the others (every entry when the fast stretch is off)
+        std::vector<int32_t> bucket[2][16][16];
         for (int64_t s = b; s < e; s++) {
             const int32_t m0 = L.slice_block[s] * C;
             const int64_t so = L.slice_off[s];
@@ -667,32 +691,37 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
                 if (L.wide) { L.wide_idx[slot] = local; L.wide_val[slot] = val[q]; }
                 else L.packed[slot] = ((uint32_t)val[q] << kPackedCountShift) | ((local * (uint32_t)L.row_slots) << 4);
             };
+            auto phase_of = [&](int64_t q) { return (fast_ones && val[q] == 1.0) ? 0 : 1; };
             if (!schedule) {
                 for (int lane = 0; lane < kLanes; lane++) {
                     size_t id = (size_t)s * kLanes + lane;
                     if (L.task_major[id] == kIdleLane) continue;
-                    for (int64_t t = 0; t < task_len[id]; t++) put(lane, t, task_pos[id] + t);
+                    int64_t t = 0;
+                    for (int ph = 0; ph < 2; ph++)
+                        for (int64_t u = 0; u < task_len[id]; u++)
+                            if (phase_of(task_pos[id] + u) == ph) put(lane, t++, task_pos[id] + u);
                 }
                 continue;
             }
             for (int g = 0; g < 4; g++) {
                 int lanes[16], nl = 0;
                 for (int lane = 0; lane < kLanes; lane++) if (kGroupOf[lane] == g) lanes[nl++] = lane;
-                int cnt[16][16] = {}, rem[16] = {}, step[16] = {}, dem[16] = {}, nopt[16] = {};
+                int cnt[2][16][16] = {}, rem[2][16] = {}, step[16] = {}, dem[16] = {}, nopt[2][16] = {};
                 int T = 0;
                 for (int j = 0; j < 16; j++) {
-                    for (int r = 0; r < 16; r++) bucket[j][r].clear();
+                    for (int ph = 0; ph < 2; ph++) for (int r = 0; r < 16; r++) bucket[ph][j][r].clear();
                     size_t id = (size_t)s * kLanes + lanes[j];
                     if (L.task_major[id] == kIdleLane) continue;
                     const int64_t q0 = task_pos[id];
                     for (int32_t t = task_len[id] - 1; t >= 0; t--) {      // reversed: stacks pop in ascending minor order
+                        const int ph = phase_of(q0 + t);
                         int r = (idx[q0 + t] - m0) & 15;
-                        bucket[j][r].push_back(t);
-                        if (cnt[j][r]++ == 0) nopt[j]++;      // nopt[j]: residues lane j still has entries of
-                        dem[r]++;
+                        bucket[ph][j][r].push_back(t);
+                        if (cnt[ph][j][r]++ == 0) nopt[ph][j]++;      // nopt: residues the lane still has entries of, per phase
+                        rem[ph][j]++;
                     }
-                    rem[j] = task_len[id];
-                    T = std::max(T, rem[j]);
+                    for (int r = 0; r < 16; r++) dem[r] += cnt[rem[0][j] > 0 ? 0 : 1][j][r];   // demand of the lanes' CURRENT phases
+                    T = std::max(T, rem[0][j] + rem[1][j]);
                 }
                 for (int t = 0; t < T; t++) {
                     int used[16] = {};
@@ -700,29 +729,37 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
                     int ord[16];
                     for (int r = 0; r < 16; r++) ord[r] = r;
                     std::stable_sort(ord, ord + 16, [&](int x, int y) { return dem[x] > dem[y]; });
+                    auto cur = [&](int j) { return rem[0][j] > 0 ? 0 : 1; };
                     auto take = [&](int j, int r) {
                         size_t id = (size_t)s * kLanes + lanes[j];
-                        int32_t tt = bucket[j][r].back();
-                        bucket[j][r].pop_back();
+                        const int ph = cur(j);
+                        int32_t tt = bucket[ph][j][r].back();
+                        bucket[ph][j][r].pop_back();
                         put(lanes[j], step[j]++, task_pos[id] + tt);
-                        assigned[j] = true; used[r]++; dem[r]--; rem[j]--;
-                        if (--cnt[j][r] == 0) nopt[j]--;
+                        assigned[j] = true; used[r]++; dem[r]--; rem[ph][j]--;
+                        if (--cnt[ph][j][r] == 0) nopt[ph][j]--;
+                        if (ph == 0 && rem[0][j] == 0)                        // the lane moves on to its other entries
+                            for (int q = 0; q < 16; q++) dem[q] += cnt[1][j][q];
                     };
                     for (int oi = 0; oi < 16; oi++) {
                         const int r = ord[oi];
                         if (dem[r] == 0) break;
                         int best = -1, best_opt = 99, best_cnt = -1;
                         for (int j = 0; j < 16; j++) {
-                            if (assigned[j] || rem[j] == 0 || cnt[j][r] == 0) continue;
-                            if (nopt[j] < best_opt || (nopt[j] == best_opt && cnt[j][r] > best_cnt)) { best = j; best_opt = nopt[j]; best_cnt = cnt[j][r]; }
+                            if (assigned[j]) continue;
+                            const int ph = cur(j);
+                            if (rem[ph][j] == 0 || cnt[ph][j][r] == 0) continue;
+                            if (nopt[ph][j] < best_opt || (nopt[ph][j] == best_opt && cnt[ph][j][r] > best_cnt)) { best = j; best_opt = nopt[ph][j]; best_cnt = cnt[ph][j][r]; }
                         }
                         if (best >= 0) take(best, r);
                     }
                     for (int j = 0; j < 16; j++) {
-                        if (assigned[j] || rem[j] == 0) continue;
+                        if (assigned[j]) continue;
+                        const int ph = cur(j);
+                        if (rem[ph][j] == 0) continue;
                         int best = -1;
                         for (int r = 0; r < 16; r++) {
-                            if (cnt[j][r] == 0) continue;
+                            if (cnt[ph][j][r] == 0) continue;
                             if (best < 0 || used[r] < used[best] || (used[r] == used[best] && dem[r] > dem[best])) best = r;
                         }
                         take(j, best);
@@ -912,7 +949,7 @@ int vbnmf_layout_build(const vbnmf_matrix *X, int64_t col_begin, int64_t col_end
     view->block_width = L.block_width; view->n_blocks = L.n_blocks; view->max_len = L.max_len; view->n_wg = L.n_wg;
     view->n_tasks = L.n_tasks; view->n_slices = L.n_slices; view->n_slots = L.n_slots; view->n_segs = L.n_segs;
     view->task_major = L.task_major.data(); view->slice_width = L.slice_width.data();
-    view->slice_off = L.slice_off.data(); view->slice_block = L.slice_block.data();
+    view->slice_off = L.slice_off.data(); view->slice_block = L.slice_block.data(); view->slice_fast = L.slice_fast.data();
     view->seg_block = L.seg_block.data(); view->wg_seg0 = L.wg_seg0.data();
     view->seg_ptr = L.seg_ptr.data(); view->row_slots = L.row_slots;
     view->inv_ptr = L.inv_ptr.data(); view->inv_task = L.inv_task.data();

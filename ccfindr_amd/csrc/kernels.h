@@ -42,6 +42,7 @@ struct SweepSide {
     const double *wval;            // value                                 (wide layout)
     const uint32_t *task_major;    // [n_slices][64]
     const int32_t *slice_width;    // [n_slices]
+    const int32_t *slice_fast;     // [n_slices] leading entries per lane that are stored ones in every lane (multiple of 8)
     const int64_t *slice_off;      // [n_slices]
     const int32_t *seg_block;      // [n_segs]
     const int32_t *wg_seg0;        // [n_wg + 1]
@@ -65,6 +66,8 @@ struct SweepRegs {
     double F[R];
     double acc[R];
     double lsum;
+    double prod;                   // running product of wth over the slice's leading ones, kept in [0.25, 1) ...
+    int pexp;                      // ... with its binary exponent here: sum ln(wth) = pexp ln 2 + ln(prod)
 };
 
 // A 4-entry group of the packed stream, unpacked: LDS byte offset of the minor's row and the count.
@@ -80,6 +83,11 @@ struct Group4 {
 __device__ __forceinline__ void pin(Group4 &g)
 {
     asm volatile("" : "+v"(g.o0), "+v"(g.o1), "+v"(g.o2), "+v"(g.o3), "+v"(g.c0), "+v"(g.c1), "+v"(g.c2), "+v"(g.c3));
+}
+// the same for a trip that does not read the counts (the leading ones of a slice): only the row offsets are pinned
+__device__ __forceinline__ void pin_offsets(Group4 &g)
+{
+    asm volatile("" : "+v"(g.o0), "+v"(g.o1), "+v"(g.o2), "+v"(g.o3));
 }
 // LDS image of the sweep: [0, kLdsTabBytes) the ln table, then kLdsEvSlots per-slice evidence
 // partials, the slice ticket counter, and from kLdsRowBase on the staged factor block.
@@ -119,10 +127,31 @@ __device__ __forceinline__ Group4 unpack4(const uint4 e)
 // non-finite, and then the reference's dense X/wth (src/vbnmf_update.cpp:34) is NaN as well.
 // SPMM: the plain product instead (acc += x g: no ratio, no logarithm) -- k_spmm, for the truncated SVD of the
 // svd2 initialiser.
-template <int R, bool SPMM = false>
+// ONE: the entry is a stored one (x is not read): q = 1 / wth, and on the side that carries the evidence's
+// sum x log(wth) the logarithm is deferred -- the lane multiplies wth into a running product (renormalised every two
+// entries, so any wth in 2^+-500 is safe) and takes ONE logarithm per slice: ~2.5 instructions per entry instead of ~18.
+template <int R, bool SPMM = false, bool ONE = false>
 __device__ __forceinline__ void sweep_entry(SweepRegs<R> &S, const double2 *__restrict__ ldsG, const double2 (&gv)[R / 2],
                                             double x, bool logterm)
 {
+    if (ONE) {
+        double w0 = S.F[0] * gv[0].x, w1 = S.F[1] * gv[0].y;
+#pragma unroll
+        for (int kk = 1; kk < R / 2; kk++) {
+            w0 = fma(S.F[2 * kk], gv[kk].x, w0);
+            w1 = fma(S.F[2 * kk + 1], gv[kk].y, w1);
+        }
+        const double wth = w0 + w1;
+        const double rc = sp_rcp_seed(wth);
+        const double q = fma(fma(-wth, rc, 1.0), rc, rc);          // 1 / wth to 2^-48, as dev_div_fast
+#pragma unroll
+        for (int kk = 0; kk < R / 2; kk++) {
+            S.acc[2 * kk] = fma(q, gv[kk].x, S.acc[2 * kk]);
+            S.acc[2 * kk + 1] = fma(q, gv[kk].y, S.acc[2 * kk + 1]);
+        }
+        if (logterm) S.prod *= wth;
+        return;
+    }
     if (SPMM) {
 #pragma unroll
         for (int kk = 0; kk < R / 2; kk++) {
@@ -146,6 +175,14 @@ __device__ __forceinline__ void sweep_entry(SweepRegs<R> &S, const double2 *__re
         S.acc[2 * kk + 1] = fma(q, gv[kk].y, S.acc[2 * kk + 1]);
     }
     if (logterm) S.lsum = fma(x, dev_log_tab(wth, reinterpret_cast<const LogTabEntry *>(ldsG)), S.lsum);
+}
+
+template <int R>
+__device__ __forceinline__ void renorm_product(SweepRegs<R> &S)
+{
+    int k;
+    S.prod = sp_frexp(S.prod, &k);
+    S.pexp += k;
 }
 
 // Next slice ticket of the workgroup, wave-uniform by construction: EVERY lane adds 1 to the LDS counter (the
@@ -226,6 +263,8 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
 #pragma unroll
             for (int k = 0; k < R; k++) T.acc[k] = 0.0;
             T.lsum = 0.0;
+            T.prod = 1.0;
+            T.pexp = 0;
 
             // Slice widths are multiples of 8: two 4-entry groups per trip, the loads of the
             // next trip issued before this trip's arithmetic, LDS rows fetched one entry ahead.
@@ -250,30 +289,47 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
                 // FENCE keeps the machine scheduler from sinking a row's LDS reads down to their first
                 // use: the reads of entry j+1 stay in front of the arithmetic of entry j, which hides them.
 #define VBNMF_FENCE() __builtin_amdgcn_sched_barrier(0)
-                for (int p = 0; p < np; p++) {
-                    const int pn = min(p + 1, np - 1);                    // last trip re-reads itself
-                    const uint4 ec = E[(size_t)pn * 128], ed = E[(size_t)pn * 128 + 64];
-                    lds_row<R>(ldsG, a.o1, g1); VBNMF_FENCE();
-                    sweep_entry<R, EV == 3>(T, ldsG, g0, (double)a.c0, LOGTERM); VBNMF_FENCE();
-                    lds_row<R>(ldsG, a.o2, g0); VBNMF_FENCE();
-                    sweep_entry<R, EV == 3>(T, ldsG, g1, (double)a.c1, LOGTERM); VBNMF_FENCE();
-                    lds_row<R>(ldsG, a.o3, g1); VBNMF_FENCE();
-                    sweep_entry<R, EV == 3>(T, ldsG, g0, (double)a.c2, LOGTERM); VBNMF_FENCE();
-                    lds_row<R>(ldsG, b.o0, g0); VBNMF_FENCE();
-                    sweep_entry<R, EV == 3>(T, ldsG, g1, (double)a.c3, LOGTERM); VBNMF_FENCE();
-                    lds_row<R>(ldsG, b.o1, g1); VBNMF_FENCE();
-                    sweep_entry<R, EV == 3>(T, ldsG, g0, (double)b.c0, LOGTERM); VBNMF_FENCE();
-                    lds_row<R>(ldsG, b.o2, g0); VBNMF_FENCE();
-                    sweep_entry<R, EV == 3>(T, ldsG, g1, (double)b.c1, LOGTERM); VBNMF_FENCE();
-                    lds_row<R>(ldsG, b.o3, g1); VBNMF_FENCE();
-                    sweep_entry<R, EV == 3>(T, ldsG, g0, (double)b.c2, LOGTERM); VBNMF_FENCE();
-                    a = unpack4<R>(ec);
-                    pin(a);
-                    lds_row<R>(ldsG, a.o0, g0); VBNMF_FENCE();
-                    sweep_entry<R, EV == 3>(T, ldsG, g1, (double)b.c3, LOGTERM); VBNMF_FENCE();
-                    b = unpack4<R>(ed);
-                    pin(b);
+                // One trip = 8 entries (two 4-entry groups).  ONE = the trip lies in the slice's leading stretch of
+                // stored ones (layout: slice_fast), PIN = the matching pin of the next trip's unpacked groups.
+#define VBNMF_ENTRY(ONE, gv, cnt) sweep_entry<R, EV == 3, ONE>(T, ldsG, gv, (double)(cnt), LOGTERM); VBNMF_FENCE()
+#define VBNMF_TRIP(ONE, PIN)                                                                      \
+                {                                                                                 \
+                    const int pn = min(p + 1, np - 1);                    /* last trip re-reads itself */ \
+                    const uint4 ec = E[(size_t)pn * 128], ed = E[(size_t)pn * 128 + 64];          \
+                    lds_row<R>(ldsG, a.o1, g1); VBNMF_FENCE();                                    \
+                    VBNMF_ENTRY(ONE, g0, a.c0);                                                   \
+                    lds_row<R>(ldsG, a.o2, g0); VBNMF_FENCE();                                    \
+                    VBNMF_ENTRY(ONE, g1, a.c1);                                                   \
+                    if (ONE && LOGTERM) renorm_product<R>(T);                                     \
+                    lds_row<R>(ldsG, a.o3, g1); VBNMF_FENCE();                                    \
+                    VBNMF_ENTRY(ONE, g0, a.c2);                                                   \
+                    lds_row<R>(ldsG, b.o0, g0); VBNMF_FENCE();                                    \
+                    VBNMF_ENTRY(ONE, g1, a.c3);                                                   \
+                    if (ONE && LOGTERM) renorm_product<R>(T);                                     \
+                    lds_row<R>(ldsG, b.o1, g1); VBNMF_FENCE();                                    \
+                    VBNMF_ENTRY(ONE, g0, b.c0);                                                   \
+                    lds_row<R>(ldsG, b.o2, g0); VBNMF_FENCE();                                    \
+                    VBNMF_ENTRY(ONE, g1, b.c1);                                                   \
+                    if (ONE && LOGTERM) renorm_product<R>(T);                                     \
+                    lds_row<R>(ldsG, b.o3, g1); VBNMF_FENCE();                                    \
+                    VBNMF_ENTRY(ONE, g0, b.c2);                                                   \
+                    a = unpack4<R>(ec);                                                           \
+                    PIN(a);                                                                       \
+                    lds_row<R>(ldsG, a.o0, g0); VBNMF_FENCE();                                    \
+                    VBNMF_ENTRY(ONE, g1, b.c3);                                                   \
+                    if (ONE && LOGTERM) renorm_product<R>(T);                                     \
+                    b = unpack4<R>(ed);                                                           \
+                    PIN(b);                                                                       \
                 }
+                const int npf = (EV == 3) ? 0 : min(np, S.slice_fast[s] >> 3);
+                int p = 0;
+                for (; p < npf - 1; p++) VBNMF_TRIP(true, pin_offsets)
+                if (p < npf) { VBNMF_TRIP(true, pin) p++; }               // the next trip reads the counts again
+                for (; p < np; p++) VBNMF_TRIP(false, pin)
+                if (LOGTERM && npf > 0)                                   // the deferred logarithm of the leading ones
+                    T.lsum += fma((double)T.pexp, 6.93147180559945286227e-01, dev_log_tab(T.prod, reinterpret_cast<const LogTabEntry *>(ldsG)));
+#undef VBNMF_TRIP
+#undef VBNMF_ENTRY
 #undef VBNMF_FENCE
             } else {
                 double2 g1[R / 2];

@@ -334,6 +334,9 @@ typedef struct {
     const int64_t *slice_off;      /* [n_slices] first slot of the slice; slot(t, lane) =
                                       off + (t/4)*256 + lane*4 + t%4 */
     const int32_t *slice_block;    /* [n_slices] minor block */
+    const int32_t *slice_fast;     /* [n_slices] leading entries per lane that are stored ones (value exactly 1) in EVERY
+                                      lane of the slice (multiple of 8; 0 for wide layouts): the sweep runs them through
+                                      a shorter loop.  A task's ones come first, its other entries after them. */
     const int32_t *seg_block;      /* [n_segs] */
     const int32_t *wg_seg0;        /* [n_wg+1] segments of each workgroup */
     const int32_t *seg_ptr;        /* [n_segs+1] first slice of each segment; slices are numbered in processing order */

@@ -21,6 +21,7 @@ def build_layout(M, side, r, cols=None):
         out["slice_width"] = arr(v.slice_width, v.n_slices)
         out["slice_off"] = arr(v.slice_off, v.n_slices)
         out["slice_block"] = arr(v.slice_block, v.n_slices)
+        out["slice_fast"] = arr(v.slice_fast, v.n_slices)
         out["seg_block"] = arr(v.seg_block, v.n_segs)
         out["seg_ptr"] = arr(v.seg_ptr, v.n_segs + 1)
         out["wg_seg0"] = arr(v.wg_seg0, v.n_wg + 1)
@@ -49,6 +50,7 @@ def reconstruct(view):
         w, off = view["slice_width"][s], view["slice_off"][s]
         assert w % 8 == 0 and w >= 8 and w <= view["max_len"] and off % 256 == 0
         lens = []
+        ones = []                                                  # per lane: its leading stretch of stored ones
         for lane in range(64):
             tid = s * 64 + lane
             M = view["task_major"][tid]
@@ -62,6 +64,7 @@ def reconstruct(view):
             if M == 0xFFFFFFFF:
                 assert not val.any() and not idx.any()
                 lens.append(0)
+                ones.append(0)
                 continue
             ntask += 1
             live = val != 0
@@ -77,8 +80,18 @@ def reconstruct(view):
             np.add.at(npart, (np.full(cols.size, M), cols), (val[live] != 16383).astype(np.int64))
             first_minor[tid] = int(cols.min())
             lens.append(n_live)
-        assert lens == sorted(lens, reverse=True)              # longest task first: width = first lane
+            if view["wide"]:
+                ones.append(0)
+            else:
+                is1 = val[:n_live] == 1.0                          # a task's ones come first, its other entries after them
+                n1 = int(is1.sum())
+                assert is1[:n1].all()
+                ones.append(n1)
+        padded = [(q + 7) // 8 for q in lens]
+        assert padded == sorted(padded, reverse=True)          # longest (padded) task first: width = first lane
         assert (w - lens[0]) < 8
+        fast = int(view["slice_fast"][s])
+        assert fast % 8 == 0 and 0 <= fast <= min(ones) and (view["wide"] == 0 or fast == 0)
     assert ntask == view["n_tasks"]
     multi = nslot > 1
     assert (npart[multi] <= 1).all() and (not multi.any() or not view["wide"])      # no entry stored twice
