@@ -270,17 +270,30 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
             // next trip issued before this trip's arithmetic, LDS rows fetched one entry ahead.
             const int np = ng >> 1;
             double2 g0[R / 2];
-            if (R > 28 && !WIDE) {
+            if (R >= VBNMF_ONEBUF_FROM && !WIDE) {
                 // very large ranks: the factor row, the accumulators and ONE gathered row already fill
                 // the register file, so no second row buffer and no look-ahead here
                 const uint4 *E = reinterpret_cast<const uint4 *>(S.packed + off) + lane;
-                for (int g = 0; g < ng; g++) {
+                const int ngf = (EV == 3) ? 0 : min(ng, S.slice_fast[s] >> 2);      // groups inside the leading stretch of ones
+                int g = 0;
+                for (; g < ngf; g++) {
+                    const Group4 a = unpack4<R>(E[(size_t)g * 64]);
+                    lds_row<R>(ldsG, a.o0, g0); sweep_entry<R, false, true>(T, ldsG, g0, 1.0, LOGTERM);
+                    lds_row<R>(ldsG, a.o1, g0); sweep_entry<R, false, true>(T, ldsG, g0, 1.0, LOGTERM);
+                    if (LOGTERM) renorm_product<R>(T);
+                    lds_row<R>(ldsG, a.o2, g0); sweep_entry<R, false, true>(T, ldsG, g0, 1.0, LOGTERM);
+                    lds_row<R>(ldsG, a.o3, g0); sweep_entry<R, false, true>(T, ldsG, g0, 1.0, LOGTERM);
+                    if (LOGTERM) renorm_product<R>(T);
+                }
+                for (; g < ng; g++) {
                     const Group4 a = unpack4<R>(E[(size_t)g * 64]);
                     lds_row<R>(ldsG, a.o0, g0); sweep_entry<R, EV == 3>(T, ldsG, g0, (double)a.c0, LOGTERM);
                     lds_row<R>(ldsG, a.o1, g0); sweep_entry<R, EV == 3>(T, ldsG, g0, (double)a.c1, LOGTERM);
                     lds_row<R>(ldsG, a.o2, g0); sweep_entry<R, EV == 3>(T, ldsG, g0, (double)a.c2, LOGTERM);
                     lds_row<R>(ldsG, a.o3, g0); sweep_entry<R, EV == 3>(T, ldsG, g0, (double)a.c3, LOGTERM);
                 }
+                if (LOGTERM && ngf > 0)
+                    T.lsum += fma((double)T.pexp, 6.93147180559945286227e-01, dev_log_tab(T.prod, reinterpret_cast<const LogTabEntry *>(ldsG)));
             } else if (!WIDE) {
                 double2 g1[R / 2];
                 const uint4 *E = reinterpret_cast<const uint4 *>(S.packed + off) + lane;
@@ -733,7 +746,7 @@ __device__ inline int dev_hyper_update_pair(const int32_t *flags, const double *
     if (flags[0] + flags[1] + flags[2] + flags[3] == 0) return 0;                          // :4
     double a0 = hyper[2 * lane];                           // aw (lane 0) or ah (lane 1)
     const double b0 = hyper[2 * lane + 1];                 // bw or bh
-    const double lm = stats[lane], em = stats[2 + lane];   // mean log l, mean e of this side (:8-11)
+    const double lm = lane ? stats[1] : stats[0], em = lane ? stats[3] : stats[2];   // mean log l, mean e of this side (:8-11)
     const int fa = flags[2 * lane];
     double a1 = a0;
     int failed = 0;
