@@ -100,3 +100,26 @@ def test_nan_state_stops_the_device_loop_with_reason_1():
     out = eng.run(HY1, Itmax=50)
     assert out["it"] == 1 and out["reason"] == 1 and np.isnan(out["lkh"])
     eng.close()
+
+
+def test_degenerate_hyper_newton_ends_with_a_reason_not_a_hang():
+    """fudge = 0 with a tiny Gamma shape: exp(psi(alw)) underflows to 0 for entries without counts, the mean log
+    statistic becomes -inf and the reference's step-halving loop (R/bayesian.R:28-35) would never end -- on the GPU
+    that would be a wedged device.  The device loop must come back with reason 3 (hyper update failed, reported as
+    the reference's error) or 1 (NaN evidence), and the host mirror must raise instead of spinning."""
+    import ccfindr_amd as C
+    from ccfindr_amd import bayesian, synth
+    X = synth.drop_empty(synth.simulate_data(60, (40, 50), seed=3, sparse=False))
+    n, m = X.shape
+    hy = {"aw": 1e-4, "bw": 1.0, "ah": 1e-4, "bh": 1.0}
+    wh = synth.random_state(n, m, 2, HY1, seed=2)
+    eng = C.VBEngine(C.CountMatrix(X), 2)
+    eng.set_state(wh["lw"], wh["lh"], wh["eh"])
+    try:
+        res = eng.run(hy, Itmax=40, Tol=1e-5, n0=2, dn=1, flags=(True,) * 4, fudge=0.0)
+        assert res["reason"] in (1, 4) or res["it"] < 40, res        # ended by a rule, not by luck
+    except RuntimeError as exc:
+        assert "failed to converge" in str(exc)                       # reason 3, raised as the reference's stop()
+    eng.close()
+    with pytest.raises((RuntimeError, ValueError)):
+        bayesian.hyper_update((True,) * 4, (-np.inf, -1.0, 0.5, 0.5), {"aw": 1e-4, "bw": 1.0, "ah": 1.0, "bh": 1.0})
