@@ -108,6 +108,9 @@ SIGNATURES = {
                                            _I32, _D, _D, c_double_p, c_double_p, c_double_p]),
     "vbnmf_engine_cluster_ids": (ctypes.c_int, [_VP, c_int32_p]),
     "vbnmf_engine_spmm": (ctypes.c_int, [_VP, _I32, c_double_p, c_double_p]),
+    "vbnmf_engine_cluster_changes": (ctypes.c_int, [_VP, c_int64_p, c_int32_p]),
+    "vbnmf_engine_random_state": (ctypes.c_int, [_VP, _D, _D, _D, _D, ctypes.c_uint64]),
+    "vbnmf_engine_svd": (ctypes.c_int, [_VP, _I32, _D, _I32, ctypes.c_uint64, c_double_p, c_double_p, c_double_p, c_int32_p]),
     "vbnmf_layout_build": (ctypes.c_int, [_VP, _I64, _I64, _I32, _I32, _VPP, ctypes.POINTER(LayoutView)]),
     "vbnmf_layout_destroy": (None, [_VP]),
     "vbnmf_test_special_host": (ctypes.c_int, [_I32, _I64, c_double_p, c_double_p]),

@@ -273,11 +273,15 @@ def vb_run_rank(irun, rank, bundle):
     hyper = {"aw": float(ga[0]), "ah": float(ga[-1]), "bw": float(gb[0]), "bh": float(gb[-1])}   # :321-326
     rng = _bundle_rng(bundle, irun, rank)
     raw = bundle.get("raw")
-    wh0 = vb_init(nrow, ncol, raw if raw is not None else X, rank, hyper=hyper, initializer=bundle["initializer"], rng=rng,
-                  device=bundle.get("device", 0))
     eng = _make_engine(bundle, rank)
+    on_device = bundle.get("device_init") and bundle["initializer"] == "random" and hasattr(eng, "random_state")
+    wh0 = None if on_device else vb_init(nrow, ncol, raw if raw is not None else X, rank, hyper=hyper,
+                                         initializer=bundle["initializer"], rng=rng, device=bundle.get("device", 0))
     try:
-        eng.set_state(wh0["lw"], wh0["lh"], wh0["eh"])
+        if on_device:
+            eng.random_state(hyper, int(rng.integers(1 << 63)))                  # :111-115 on the GPU
+        else:
+            eng.set_state(wh0["lw"], wh0["lh"], wh0["eh"])
         lk0 = 0.0
         it = 0
         device_loop = bundle.get("device_loop", True) and verbose < 3 and hasattr(eng, "run")
@@ -398,7 +402,8 @@ def make_bundle(mat, ranks, nrun, verbose, initializer, Itmax, hyper_update, gam
 def vb_factorize(mat, ranks=2, nrun=1, verbose=2, progress_bar=True, initializer="random", Itmax=10000,
                  hyper_update=(True, True, True, True), gamma_a=1, gamma_b=1, Tol=1e-5,
                  hyper_update_n0=10, hyper_update_dn=1, connectivity=False, fudge=None, ncores=1,
-                 useC=True, unif_stop=True, seed=None, device=0, engine_factory=None, device_loop=True, concurrent=1):
+                 useC=True, unif_stop=True, seed=None, device=0, engine_factory=None, device_loop=True, concurrent=1,
+                 device_init=False):
     """Bayesian NMF of a count matrix on the MI355X engine; reference R/bayesian.R:229-301.
 
     ``mat`` is the genes x cells count matrix (dense, scipy sparse, or ``CountMatrix``).
@@ -413,6 +418,9 @@ def vb_factorize(mat, ranks=2, nrun=1, verbose=2, progress_bar=True, initializer
     the chip idle), so independent factorisations overlap almost for free.  Every unit draws from its own seeded
     stream, so the result does not depend on ``concurrent``; with ``unif_stop`` a run's ranks beyond a constant
     basis column are still computed (and then discarded, as the sharded driver does).
+    ``device_init`` draws the ``random`` initial state on the GPU (``vbnmf_engine_random_state``: Philox counters +
+    Marsaglia-Tsang, one key per (seed, run, rank)) instead of with numpy on the host; off by default so that runs
+    with an injected engine and runs on the HIP engine start from the same arrays.
     """
     del progress_bar, useC, ncores
     if connectivity:
@@ -420,6 +428,7 @@ def vb_factorize(mat, ranks=2, nrun=1, verbose=2, progress_bar=True, initializer
     bundle = make_bundle(mat, ranks, nrun, verbose, initializer, Itmax, hyper_update, gamma_a, gamma_b, Tol,
                          hyper_update_n0, hyper_update_dn, fudge, unif_stop, seed, device, engine_factory)
     bundle["device_loop"] = bool(device_loop)      # False: step from the host (the loop below, literally)
+    bundle["device_init"] = bool(device_init)
     bundle["concurrent"] = max(1, int(concurrent))
     bundle["engines"] = {} if (nrun > 1 or bundle["concurrent"] > 1) else None   # restarts of a rank reuse its engine
     try:

@@ -26,6 +26,7 @@
 #include "comm.h"
 #include "kernels.h"
 #include "mlnmf.h"
+#include "init.h"
 
 using namespace vbnmf;
 
@@ -100,6 +101,13 @@ struct vbnmf_engine {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int64_t n = 0, m = 0, m_global = 0, nnz = 0;
+    int64_t col_begin = 0;            // first cell of this partition (0 for an unpartitioned engine)
+    int32_t *d_ids[2] = {nullptr, nullptr};   // arg-max labels of the cells: current / previous (cluster_changes)
+    int ids_cur = 0;
+    bool ids_valid = false;
+    unsigned long long *d_table = nullptr;    // [(r+1)^2 + 1] contingency table of two labelings, then the pair count
+    double *svd_ws = nullptr;         // truncated SVD work space: Gram block partials, two k x k matrices, values
+    int32_t *svd_status = nullptr;
     int r = 0, R = 0, NT = 0, n_wg = 0;
     bool wide = false, partitioned = false;
     double lgx = 0.0;
@@ -511,6 +519,21 @@ int check_device(int device)
     return VBNMF_OK;
 }
 
+// Statistics of a freshly loaded state (lw, lh, eh on the device): rowSum(eh), then the sweep (its evidence partials
+// are not used); a partitioned engine leaves them in the reduce buffer for the exchange (state_finish follows).
+int prime_state(vbnmf_engine *e)
+{
+    e->has_state = true;
+    e->ids_valid = false;
+    if (int rc = launch_prime(e, true)) return rc;
+    if (int rc = launch_prime(e, false)) return rc;
+    if (int rc = launch_sweep(e)) return rc;
+    if (e->partitioned) { if (int rc = launch_pack(e)) return rc; }
+    e->prime_pending = true;
+    if (!e->partitioned) return vbnmf_engine_state_finish(e);
+    return VBNMF_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -536,6 +559,7 @@ void vbnmf_engine_destroy(vbnmf_engine *e)
     (void)hipFree(e->lw); (void)hipFree(e->llw); (void)hipFree(e->ew); (void)hipFree(e->dw);
     (void)hipFree(e->lh); (void)hipFree(e->llh); (void)hipFree(e->eh); (void)hipFree(e->dh);
     (void)hipFree(e->epart); (void)hipFree(e->bpW); (void)hipFree(e->bpH);
+    (void)hipFree(e->d_ids[0]); (void)hipFree(e->d_ids[1]); (void)hipFree(e->d_table); (void)hipFree(e->svd_ws); (void)hipFree(e->svd_status);
     (void)hipFree(e->red); (void)hipFree(e->red_g); (void)hipFree(e->d_out);
     for (hipEvent_t ev : e->ev_ring) (void)hipEventDestroy(ev);
     if (e->cstream) (void)hipStreamDestroy(e->cstream); (void)hipFree(e->dbg); (void)hipFree(e->logtab); (void)hipFree(e->ctl);
@@ -570,7 +594,7 @@ int vbnmf_engine_create_part(const vbnmf_matrix *X, int64_t cb, int64_t ce, int6
     vbnmf_engine *e = new (std::nothrow) vbnmf_engine();
     if (!e) return fail(VBNMF_ERR_OOM, "out of host memory");
     e->device = device;
-    e->n = X->M.n; e->m = ce - cb; e->m_global = m_global;
+    e->n = X->M.n; e->m = ce - cb; e->m_global = m_global; e->col_begin = cb;
     e->r = r; e->R = padded_rank(r);
     e->NT = sweep_threads(e->R);
     e->wide = !X->M.counts_int;
@@ -722,15 +746,25 @@ int vbnmf_engine_set_state(vbnmf_engine *e, const double *lw, const double *lh, 
     } catch (const std::bad_alloc &) {
         return fail(VBNMF_ERR_OOM, "out of host memory staging the state");
     }
-    e->has_state = true;
-    // statistics of the loaded state: rowSum(eh), then the sweep (its evidence partials are not used)
-    if (int rc = launch_prime(e, true)) return rc;
-    if (int rc = launch_prime(e, false)) return rc;
-    if (int rc = launch_sweep(e)) return rc;
-    if (e->partitioned) { if (int rc = launch_pack(e)) return rc; }
-    e->prime_pending = true;
-    if (!e->partitioned) return vbnmf_engine_state_finish(e);
-    return VBNMF_OK;
+    return prime_state(e);
+}
+
+// The 'random' initialiser of vb_init (reference R/bayesian.R:111-115, 162-170) drawn on the device (init.h):
+// lw = ew ~ Gamma(shape aw, scale bw / aw), lh = eh ~ Gamma(ah, bh / ah), dw = dh = 0, then the statistics of that state.
+int vbnmf_engine_random_state(vbnmf_engine *e, double aw, double bw, double ah, double bh, uint64_t seed)
+{
+    if (!e) return fail(VBNMF_ERR_BAD_ARG, "engine handle is NULL");
+    if (!(aw > 0.0) || !(bw > 0.0) || !(ah > 0.0) || !(bh > 0.0)) return fail(VBNMF_ERR_BAD_ARG, "Gamma shapes and means must be positive");
+    if (int rc = use_device(e)) return rc;
+    e->has_state = false; e->stats_ready = false; e->step_pending = false; e->prime_pending = false;
+    e->ml_ready = false; e->ids_valid = false;
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    const int64_t nw = e->n * e->R, nh = e->m * e->R;
+    hipLaunchKernelGGL(k_gamma_init, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, e->stream, e->lw, e->ew, e->dw, e->n, (int64_t)0, e->r, e->R, aw, bw, 0u, k0, k1);
+    HIPCHECK(hipGetLastError());
+    hipLaunchKernelGGL(k_gamma_init, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, e->stream, e->lh, e->eh, e->dh, e->m, e->col_begin, e->r, e->R, ah, bh, 1u, k0, k1);
+    HIPCHECK(hipGetLastError());
+    return prime_state(e);
 }
 
 int vbnmf_engine_state_finish(vbnmf_engine *e)
@@ -1309,7 +1343,7 @@ int vbnmf_engine_ml_set_state(vbnmf_engine *e, const double *w, const double *h)
     if (!e || !w || !h) return fail(VBNMF_ERR_BAD_ARG, "NULL argument");
     if (e->partitioned) return fail(VBNMF_ERR_STATE, "ML-NMF needs an unpartitioned engine");
     if (int rc = use_device(e)) return rc;
-    e->has_state = false; e->stats_ready = false; e->step_pending = false; e->prime_pending = false; e->ml_ready = false;
+    e->has_state = false; e->stats_ready = false; e->step_pending = false; e->prime_pending = false; e->ml_ready = false; e->ids_valid = false;
     try {
         std::vector<double> tmp;
         to_index_major(w, e->n, e->r, e->R, false, tmp);
@@ -1470,6 +1504,212 @@ int vbnmf_engine_cluster_ids(vbnmf_engine *e, int32_t *ids)
     if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
     (void)hipFree(d_ids);
     if (he != hipSuccess) return fail(VBNMF_ERR_HIP, "cluster_ids failed: %s", hipGetErrorString(he));
+    return VBNMF_OK;
+}
+
+// The connectivity stopping count of factorize() (reference R/factorize.R:198-208) on the device: the labels of the
+// state held now against the labels of the previous call, as sum(cnn != cnn0) over all pairs of cells -- from the
+// contingency table of the two labelings, never from the O(m^2) vectors.  changed = -1 on the first call after a
+// state was loaded (the reference starts from nchange = npair, :200).  ids (optional): the new labels, m_local int32.
+int vbnmf_engine_cluster_changes(vbnmf_engine *e, int64_t *changed, int32_t *ids)
+{
+    if (!e || !changed) return fail(VBNMF_ERR_BAD_ARG, "NULL argument");
+    if (!e->ml_ready && !e->has_state) return fail(VBNMF_ERR_STATE, "cluster_changes before a state was loaded");
+    if (int rc = use_device(e)) return rc;
+    for (int q = 0; q < 2; q++)
+        if (!e->d_ids[q]) { if (int rc = dev_alloc(&e->d_ids[q], (size_t)e->m)) return rc; }
+    const size_t tcount = (size_t)(e->r + 1) * (e->r + 1) + 1;
+    if (!e->d_table) { if (int rc = dev_alloc(&e->d_table, tcount)) return rc; }
+    const double *h = e->ml_ready ? e->lh : e->eh;
+    const int cur = e->ids_cur ^ 1;
+    hipLaunchKernelGGL(k_argmax, dim3((unsigned)((e->m + 255) / 256)), dim3(256), 0, e->stream, h, e->m, e->r, e->R, e->d_ids[cur]);
+    HIPCHECK(hipGetLastError());
+    unsigned long long n = 0;
+    if (e->ids_valid) {
+        HIPCHECK(hipMemsetAsync(e->d_table, 0, tcount * sizeof(unsigned long long), e->stream));
+        hipLaunchKernelGGL(k_label_table, dim3((unsigned)((e->m + 255) / 256)), dim3(256), 0, e->stream, e->d_ids[cur ^ 1], e->d_ids[cur], e->m, e->r, e->d_table);
+        HIPCHECK(hipGetLastError());
+        hipLaunchKernelGGL(k_label_pairs, dim3(1), dim3(1), 0, e->stream, e->d_table, e->r, e->d_table + (tcount - 1));
+        HIPCHECK(hipGetLastError());
+        HIPCHECK(hipMemcpyAsync(&n, e->d_table + (tcount - 1), sizeof n, hipMemcpyDeviceToHost, e->stream));
+    }
+    if (ids) HIPCHECK(hipMemcpyAsync(ids, e->d_ids[cur], (size_t)e->m * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+    HIPCHECK(hipStreamSynchronize(e->stream));
+    *changed = e->ids_valid ? (int64_t)n : -1;
+    e->ids_cur = cur;
+    e->ids_valid = true;
+    return VBNMF_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+// Sparse product with the resident X on operands that are ALREADY on the device: gene side C[n][R] = X B (B = the lh
+// array, one row per cell), cell side C[m][R] = t(X) W (W = the lw array); the per-task partials are summed per
+// major straight into `target`.
+int spmm_device(vbnmf_engine *e, bool gene_side, double *target)
+{
+    SweepSide a = sweep_side_args(e, gene_side ? e->A : e->B, gene_side, gene_side ? e->epart : e->epart + e->n_wg);
+    a.logterm = 0;
+    a.stop = nullptr;
+    int rc = VBNMF_ERR_BAD_ARG;
+    switch (e->R) {
+#define X(RR) case RR: rc = launch_spmm_r<RR>(e, a); break;
+        VBNMF_FOR_EACH_R(X)
+#undef X
+        default: return fail(VBNMF_ERR_BAD_ARG, "unsupported padded rank %d", e->R);
+    }
+    if (rc) return rc;
+    const DeviceSide &S = gene_side ? e->A : e->B;
+    const int64_t cnt = (gene_side ? e->n : e->m) * e->R;
+    hipLaunchKernelGGL(k_pack, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, e->stream, S.part, S.inv_ptr, S.inv_task, gene_side ? e->n : e->m, e->R, target);
+    HIPCHECK(hipGetLastError());
+    return VBNMF_OK;
+}
+
+// work space of the truncated SVD: [gram partials kGramBlocks * R*R | S (R*R) | S2 (R*R) | vals (R)]
+struct SvdWs { double *gp, *S, *S2, *vals; };
+SvdWs svd_ws(vbnmf_engine *e)
+{
+    const size_t RR = (size_t)e->R * e->R;
+    SvdWs w;
+    w.gp = e->svd_ws; w.S = w.gp + (size_t)kGramBlocks * RR; w.S2 = w.S + RR; w.vals = w.S2 + RR;
+    return w;
+}
+
+int launch_gram(vbnmf_engine *e, const double *A, int64_t N)
+{
+    SvdWs w = svd_ws(e);
+    switch (e->R) {
+#define X(RR) case RR: hipLaunchKernelGGL((k_gram<RR>), dim3(kGramBlocks), dim3(1024), 0, e->stream, A, N, w.gp); break;
+        VBNMF_FOR_EACH_R(X)
+#undef X
+        default: return fail(VBNMF_ERR_BAD_ARG, "unsupported padded rank %d", e->R);
+    }
+    HIPCHECK(hipGetLastError());
+    return VBNMF_OK;
+}
+
+int launch_small(vbnmf_engine *e, int mode, bool want_s2, double *vals_host, double seq)
+{
+    SvdWs w = svd_ws(e);
+    switch (e->R) {
+#define X(RR) case RR: hipLaunchKernelGGL((k_small<RR>), dim3(1), dim3(1024), 0, e->stream, w.gp, kGramBlocks, e->r, mode, w.S, want_s2 ? w.S2 : nullptr, w.vals, vals_host, seq, e->svd_status); break;
+        VBNMF_FOR_EACH_R(X)
+#undef X
+        default: return fail(VBNMF_ERR_BAD_ARG, "unsupported padded rank %d", e->R);
+    }
+    HIPCHECK(hipGetLastError());
+    return VBNMF_OK;
+}
+
+int launch_apply(vbnmf_engine *e, const double *A, const double *S, int64_t N, double *B)
+{
+    switch (e->R) {
+#define X(RR) case RR: hipLaunchKernelGGL((k_apply<RR>), dim3((unsigned)((N + 255) / 256)), dim3(256), 0, e->stream, A, S, N, B); break;
+        VBNMF_FOR_EACH_R(X)
+#undef X
+        default: return fail(VBNMF_ERR_BAD_ARG, "unsupported padded rank %d", e->R);
+    }
+    HIPCHECK(hipGetLastError());
+    return VBNMF_OK;
+}
+
+// A <- orthonormal basis of range(A), A tall [N][R]: CholeskyQR twice (Gram matrix, its Cholesky factor's inverse,
+// A times that) -- the second pass repairs the orthogonality the first loses to the condition number.  When `gram_ready`
+// the block partials of t(A) A are already in the work space.
+int orthonormalise(vbnmf_engine *e, double *A, int64_t N, bool gram_ready)
+{
+    SvdWs w = svd_ws(e);
+    for (int pass = 0; pass < 2; pass++) {
+        if (!(pass == 0 && gram_ready)) { if (int rc = launch_gram(e, A, N)) return rc; }
+        if (int rc = launch_small(e, 0, false, nullptr, 0.0)) return rc;
+        if (int rc = launch_apply(e, A, w.S, N, A)) return rc;
+    }
+    return VBNMF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Truncated SVD of the resident X by block subspace iteration, ENTIRELY on the device (the
+// irlba::irlba(mat, rank) of the svd2 initialiser, reference R/bayesian.R:150-159): the subspace has k = the engine's
+// rank columns (rank_out of them are returned); per iteration two sparse products (k_spmm), two CholeskyQR2
+// orthonormalisations (k_gram / k_small / k_apply) and the k x k eigen-problem that yields the current singular values
+// (k_small, Jacobi) -- the host only reads those k values from pinned memory for the stopping rule
+// max |s - s_old| <= tol * s[0] over the leading rank_out.  No host <-> device copy inside the iteration.
+// Outputs: u (n x rank_out, column-major), d (rank_out), vt (rank_out x m, column-major), iterations done.
+int vbnmf_engine_svd(vbnmf_engine *e, int32_t rank_out, double tol, int32_t maxit, uint64_t seed, double *u, double *d,
+                     double *vt, int32_t *iterations)
+{
+    if (!e || !u || !d || !vt) return fail(VBNMF_ERR_BAD_ARG, "NULL argument");
+    if (e->partitioned) return fail(VBNMF_ERR_STATE, "the truncated SVD needs an unpartitioned engine");
+    if (rank_out < 1 || rank_out > e->r) return fail(VBNMF_ERR_BAD_ARG, "rank_out must be in [1, engine rank]");
+    if (maxit < 1) return fail(VBNMF_ERR_BAD_ARG, "maxit must be >= 1");
+    if (int rc = use_device(e)) return rc;
+    e->has_state = false; e->stats_ready = false; e->step_pending = false; e->prime_pending = false; e->ml_ready = false;
+    const size_t RR = (size_t)e->R * e->R;
+    if (!e->svd_ws) { if (int rc = dev_alloc(&e->svd_ws, (size_t)kGramBlocks * RR + 2 * RR + e->R)) return rc; }
+    if (!e->svd_status) { if (int rc = dev_alloc(&e->svd_status, 1)) return rc; }
+    HIPCHECK(hipMemsetAsync(e->svd_status, 0, sizeof(int32_t), e->stream));
+    if (int rc = ensure_history(e, (size_t)e->R + 2)) return rc;             // pinned [R values | sequence number]
+    SvdWs w = svd_ws(e);
+    volatile double *hv = e->h_hist;
+    hv[e->R] = 0.0;
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    const int64_t nh = e->m * e->R;
+    double *Q = e->lw, *Z = e->lh;                                           // n x k and m x k, index-major
+    // range finder: Q = orth(X G), G standard normal m x k
+    hipLaunchKernelGGL(k_normal_init, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, e->stream, Z, e->m, e->r, e->R, k0, k1);
+    HIPCHECK(hipGetLastError());
+    if (int rc = spmm_device(e, true, Q)) return rc;
+    if (int rc = orthonormalise(e, Q, e->n, false)) return rc;
+    std::vector<double> s_old;
+    int it = 0;
+    for (it = 1; it <= maxit; it++) {
+        if (int rc = spmm_device(e, false, Z)) return rc;                    // Z = t(X) Q
+        if (int rc = orthonormalise(e, Z, e->m, false)) return rc;
+        if (int rc = spmm_device(e, true, Q)) return rc;                     // Y = X Z = Q Rm
+        if (int rc = launch_gram(e, Q, e->n)) return rc;                     // t(Y) Y = t(Rm) Rm: eigenvalues = sigma^2
+        if (int rc = launch_small(e, 1, false, e->h_hist_dev, (double)it)) return rc;
+        if (int rc = orthonormalise(e, Q, e->n, true)) return rc;            // (the Gram partials are still in place)
+        HIPCHECK(hipStreamSynchronize(e->stream));
+        if (hv[e->R] != (double)it) return fail(VBNMF_ERR_HIP, "the singular values of iteration %d never arrived", it);
+        std::vector<double> sv(rank_out);
+        for (int q = 0; q < rank_out; q++) sv[q] = std::sqrt(std::max(0.0, (double)hv[q]));
+        bool done = false;
+        if (!s_old.empty()) {
+            double dmax = 0.0;
+            for (int q = 0; q < rank_out; q++) dmax = std::max(dmax, std::fabs(sv[q] - s_old[q]));
+            done = dmax <= tol * sv[0];
+        }
+        s_old.swap(sv);
+        if (done) break;
+    }
+    if (it > maxit) it = maxit;
+    // B = t(Q) X = t(P), P = t(X) Q (m x k): B t(B) = t(P) P = Ub D^2 t(Ub); u = Q Ub, rows of vt = P Ub / D
+    if (int rc = spmm_device(e, false, Z)) return rc;
+    if (int rc = launch_gram(e, Z, e->m)) return rc;
+    if (int rc = launch_small(e, 1, true, e->h_hist_dev, (double)(maxit + 1))) return rc;
+    if (int rc = launch_apply(e, Q, w.S, e->n, e->ew)) return rc;
+    if (int rc = launch_apply(e, Z, w.S2, e->m, e->eh)) return rc;
+    HIPCHECK(hipStreamSynchronize(e->stream));
+    int32_t status = 0;
+    HIPCHECK(hipMemcpy(&status, e->svd_status, sizeof status, hipMemcpyDeviceToHost));
+    if (status) return fail(VBNMF_ERR_STATE, "the subspace lost rank (a Gram matrix was not positive definite): fewer independent directions than the engine's rank");
+    for (int q = 0; q < rank_out; q++) d[q] = std::sqrt(std::max(0.0, (double)hv[q]));
+    try {
+        std::vector<double> tmp((size_t)std::max(e->n, e->m) * e->R);
+        HIPCHECK(hipMemcpy(tmp.data(), e->ew, (size_t)e->n * e->R * sizeof(double), hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < e->n; i++) for (int q = 0; q < rank_out; q++) u[i + (size_t)q * e->n] = tmp[(size_t)i * e->R + q];
+        HIPCHECK(hipMemcpy(tmp.data(), e->eh, (size_t)e->m * e->R * sizeof(double), hipMemcpyDeviceToHost));
+        for (int64_t j = 0; j < e->m; j++) for (int q = 0; q < rank_out; q++) vt[q + (size_t)j * rank_out] = tmp[(size_t)j * e->R + q];
+    } catch (const std::bad_alloc &) {
+        return fail(VBNMF_ERR_OOM, "out of host memory staging the singular vectors");
+    }
+    if (iterations) *iterations = it;
     return VBNMF_OK;
 }
 

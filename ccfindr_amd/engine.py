@@ -224,6 +224,31 @@ class VBEngine:
         N.check(self._lib.vbnmf_engine_cluster_ids(self._h, ids.ctypes.data_as(N.c_int32_p)))
         return ids
 
+    def cluster_changes(self, want_ids=False):
+        """``sum(cnn != cnn0)`` between the labels of the state held now and those of the previous call (reference
+        R/factorize.R:198-208), counted on the device; ``None`` on the first call after a state was loaded.
+        Returns ``(changed, ids or None)``."""
+        ch = ctypes.c_int64()
+        ids = np.empty(self.m, dtype=np.int32) if want_ids else None
+        N.check(self._lib.vbnmf_engine_cluster_changes(self._h, ctypes.byref(ch), ids.ctypes.data_as(N.c_int32_p) if want_ids else None))
+        return (None if ch.value < 0 else ch.value), ids
+
+    def random_state(self, hyper, seed):
+        """vb_init(initializer='random') drawn on the device (reference R/bayesian.R:111-115); ``seed``: 64-bit."""
+        N.check(self._lib.vbnmf_engine_random_state(self._h, float(hyper["aw"]), float(hyper["bw"]), float(hyper["ah"]),
+                                                    float(hyper["bh"]), int(seed) & 0xFFFFFFFFFFFFFFFF))
+
+    def svd(self, rank_out, tol=1e-7, maxit=60, seed=0):
+        """Leading ``rank_out`` singular triplets of the resident X by device-resident subspace iteration on
+        ``self.rank`` columns -> ``(u, d, vt, iterations)``."""
+        u = np.empty((self.n, int(rank_out)), order="F")
+        d = np.empty(int(rank_out))
+        vt = np.empty((int(rank_out), self.m), order="F")
+        it = ctypes.c_int32()
+        N.check(self._lib.vbnmf_engine_svd(self._h, int(rank_out), float(tol), int(maxit), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                           N.dptr(u), N.dptr(d), N.dptr(vt), ctypes.byref(it)))
+        return u, d, vt, it.value
+
     # -- sparse products with the resident X (truncated SVD of the svd2 initialiser) ----------
     def spmm(self, B, transpose=False):
         """``X @ B.T`` (B: r x m -> n x r) or, with ``transpose``, ``B.T @ X`` (B: n x r -> r x m); drops any state."""

@@ -191,8 +191,13 @@ def factorize(mat, ranks=2, nrun=20, randomize=False, nsmpl=1, verbose=2, progre
                     for it in (() if on_device else range(1, Itmax + 1)):          # :196
                         lk0 = eng.ml_step()                                        # :197-198
                         if criterion == "connectivity":
-                            cid = (eng.cluster_ids() - 1) if hasattr(eng, "cluster_ids") else cluster_ids(eng.ml_get_state(("eh",))["eh"])
-                            nchange = npair if it == 1 else connectivity_changes(cid0, cid, rank)   # :200-202
+                            if hasattr(eng, "cluster_changes"):            # labels, table and pair count on the device
+                                nchange, cid = eng.cluster_changes()[0], None
+                                if nchange is None or it == 1:
+                                    nchange = npair                        # :200
+                            else:
+                                cid = (eng.cluster_ids() - 1) if hasattr(eng, "cluster_ids") else cluster_ids(eng.ml_get_state(("eh",))["eh"])
+                                nchange = npair if it == 1 else connectivity_changes(cid0, cid, rank)   # :200-202
                             if verbose >= 3:
                                 say(f"{it} : likelihood =  {lk0} , connectivity change =  {nchange}")
                             zstep = zstep + 1 if nchange == 0 else 0               # :206-207

@@ -1,7 +1,7 @@
 """Truncated SVD of the count matrix on the MI355X engine: the ``irlba::irlba(mat, rank)`` of the reference's
 ``svd2`` initialiser (R/bayesian.R:150-159) with its two sparse products ``X V`` and ``t(X) U`` run by the sweep
-machinery (``vbnmf_engine_spmm``, ``k_spmm``); the k-column QR factorisations and the small k x k SVD stay on
-the host (numpy), k = rank + oversampling <= 32.
+machinery (``k_spmm``) and, by default, everything else on the device as well (``vbnmf_engine_svd``: the subspace
+never leaves HBM inside the iteration); k = rank + oversampling <= 32.
 
 irlba is an implicitly restarted Lanczos bidiagonalisation with ``tol = 1e-5``; this is block subspace iteration with
 the same kind of stopping rule (relative change of the leading singular values) and a tighter default, so the
@@ -15,8 +15,13 @@ from . import _native as N
 from .engine import CountMatrix, VBEngine
 
 
-def truncated_svd(mat, rank, tol=1e-7, maxit=60, oversample=10, seed=0, device=0):
-    """Leading ``rank`` singular triplets ``(u, d, vt)`` of the count matrix (``u`` n x rank, ``vt`` rank x m)."""
+def truncated_svd(mat, rank, tol=1e-7, maxit=60, oversample=10, seed=0, device=0, method="device"):
+    """Leading ``rank`` singular triplets ``(u, d, vt)`` of the count matrix (``u`` n x rank, ``vt`` rank x m).
+
+    ``method="device"`` (default): the whole subspace iteration runs on the GPU (``vbnmf_engine_svd``: sparse products,
+    CholeskyQR2, Jacobi eigen-solve of the k x k Gram matrix; the host reads k numbers per iteration from pinned
+    memory).  ``method="host_qr"``: the products on the GPU, the k-column QR and the small SVD in numpy (round 1's
+    form; also what the device form falls back to when X has fewer than k independent directions)."""
     M = mat if isinstance(mat, CountMatrix) else CountMatrix(mat)
     own = M is not mat
     n, m = M.shape
@@ -28,6 +33,13 @@ def truncated_svd(mat, rank, tol=1e-7, maxit=60, oversample=10, seed=0, device=0
         raise ValueError(f"rank {rank} exceeds the engine's maximum of {N.MAX_RANK}")
     eng = VBEngine(M, k, device=device)
     try:
+        if method == "device":
+            try:
+                u, d, vt, _ = eng.svd(rank, tol=tol, maxit=maxit, seed=seed)
+                return u, d, vt
+            except N.VBNMFError as exc:
+                if exc.code != N.ERR_STATE:
+                    raise                                                     # rank-deficient subspace: the QR form copes
         rng = np.random.default_rng(seed)
         Q, _ = np.linalg.qr(eng.spmm(rng.standard_normal((k, m))))        # range finder: X G
         s_old = None

@@ -299,6 +299,29 @@ int vbnmf_ml_update_csc(int64_t n, int64_t m, int32_t r, const int32_t *p, const
  * (the connectivity stopping criterion of factorize(), R/factorize.R:198-208). */
 int vbnmf_engine_cluster_ids(vbnmf_engine *e, int32_t *ids);
 
+/* The same labels compared with those of the PREVIOUS call: changed = sum(cnn != cnn0) over all pairs of cells, the
+ * stopping count of factorize() under criterion = 'connectivity' (R/factorize.R:198-208; cnn = connectivity(h),
+ * :51-60), formed on the device from the contingency table of the two labelings -- never from the O(m^2) pair
+ * vectors.  changed = -1 on the first call after a state was loaded (the reference starts from npair, :200).
+ * ids may be NULL. */
+int vbnmf_engine_cluster_changes(vbnmf_engine *e, int64_t *changed, int32_t *ids);
+
+/* vb_init(initializer = 'random') on the device (R/bayesian.R:111-115, 162-170): lw = ew ~ Gamma(shape aw, scale
+ * bw/aw), lh = eh ~ Gamma(shape ah, scale bh/ah), dw = dh = 0, followed by what set_state does (a partitioned engine
+ * needs the state exchange + state_finish).  Philox4x32-10 counters keyed by `seed`, Marsaglia-Tsang rejection; a
+ * draw depends on (seed, factor, global element index) only, so partitions of one matrix draw pieces of the same H.
+ * R's own RNG stream cannot be reproduced outside R: "identical seeds" means identical arrays, not R's numbers. */
+int vbnmf_engine_random_state(vbnmf_engine *e, double aw, double bw, double ah, double bh, uint64_t seed);
+
+/* Truncated SVD of the resident X, entirely on the device: what irlba::irlba(mat, rank) computes for the svd2
+ * initialiser (R/bayesian.R:150-159).  Block subspace iteration on k = the engine's rank columns (create the engine
+ * with rank = rank_out + oversampling): sparse products on the tiled layout, CholeskyQR2 orthonormalisation and a
+ * k x k Jacobi eigen-solve per iteration; stops when the leading rank_out singular values move by <= tol * s[0], or
+ * after maxit iterations.  u: n x rank_out, d: rank_out, vt: rank_out x m (column-major).  Drops any VB / ML state.
+ * Fails with VBNMF_ERR_STATE if X has fewer than k independent directions.  Unpartitioned engines only. */
+int vbnmf_engine_svd(vbnmf_engine *e, int32_t rank_out, double tol, int32_t maxit, uint64_t seed,
+                     double *u, double *d, double *vt, int32_t *iterations);
+
 /* ---------------------------------------------------------------------------------
  * Sparse products with the resident X, the two matrix-vector
  * blocks of a truncated SVD -- what irlba::irlba(mat, rank) computes for the svd2

@@ -91,3 +91,39 @@ def test_svd2_initialiser_on_device_matches_host_svd():
     # and through the driver: one deterministic run from that start
     res = C.vb_factorize(sp.csc_matrix(X), ranks=3, nrun=1, initializer="svd2", verbose=0, Itmax=30)
     assert res.basis[0].shape == (300, 3) and np.isfinite(res.measure["lml"][0])
+
+
+@pytest.mark.parametrize("n,m,k", [(400, 900, 4), (1200, 700, 6)])
+def test_device_resident_svd_matches_full_svd_and_the_host_qr_form(n, m, k):
+    """vbnmf_engine_svd: the whole subspace iteration on the device (CholeskyQR2 + Jacobi on the Gram matrix), against
+    numpy's full SVD and against the host-QR form of the same iteration."""
+    from ccfindr_amd.linalg import truncated_svd
+    X = planted(n, m, k, seed=n)
+    Xs = sp.csc_matrix(X)
+    u, d, vt = truncated_svd(Xs, k, method="device")
+    U, D, Vt = np.linalg.svd(X, full_matrices=False)
+    assert np.max(np.abs(d / D[:k] - 1)) <= 1e-9
+    for i in range(k):
+        assert abs(abs(u[:, i] @ U[:, i]) - 1) <= 1e-8 and abs(abs(vt[i] @ Vt[i]) - 1) <= 1e-8
+    assert np.allclose(u.T @ u, np.eye(k), atol=1e-10) and np.allclose(vt @ vt.T, np.eye(k), atol=1e-10)
+    u2, d2, vt2 = truncated_svd(Xs, k, method="host_qr")
+    assert np.max(np.abs(d / d2 - 1)) <= 1e-9
+
+
+def test_device_svd_reports_a_rank_deficient_subspace():
+    """Fewer independent directions than subspace columns: the Cholesky factor of the Gram matrix does not exist; the
+    C entry says so (VBNMF_ERR_STATE) and truncated_svd continues in the QR form."""
+    import ccfindr_amd as C
+    from ccfindr_amd.linalg import truncated_svd
+    rng = np.random.default_rng(3)
+    A = rng.poisson(2.0, size=(60, 3)).astype(np.float64) + 1
+    B = rng.poisson(2.0, size=(3, 80)).astype(np.float64) + 1
+    X = A @ B                                              # rank 3 exactly
+    eng = C.VBEngine(C.CountMatrix(X), 12)
+    with pytest.raises(C.VBNMFError) as ei:
+        eng.svd(2)
+    assert ei.value.code == 5
+    eng.close()
+    u, d, vt = truncated_svd(sp.csc_matrix(X), 2)
+    D = np.linalg.svd(X, compute_uv=False)
+    assert np.max(np.abs(d / D[:2] - 1)) <= 1e-9
