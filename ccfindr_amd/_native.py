@@ -42,7 +42,7 @@ class LayoutView(ctypes.Structure):
         ("row_slots", ctypes.c_int32),
         ("n_tasks", ctypes.c_int64), ("n_slices", ctypes.c_int64), ("n_slots", ctypes.c_int64), ("n_segs", ctypes.c_int64),
         ("task_major", c_uint32_p), ("slice_width", c_int32_p), ("slice_off", c_int64_p), ("slice_block", c_int32_p), ("slice_fast", c_int32_p),
-        ("seg_block", c_int32_p), ("wg_seg0", c_int32_p), ("seg_ptr", c_int32_p),
+        ("block_start", c_int64_p), ("seg_block", c_int32_p), ("wg_seg0", c_int32_p), ("seg_ptr", c_int32_p),
         ("inv_ptr", c_int32_p), ("inv_task", c_uint32_p),
         ("packed", c_uint32_p), ("wide_idx", c_uint32_p), ("wide_val", c_double_p),
     ]

@@ -81,13 +81,14 @@ struct Layout {
     int side = 0;                   // 0: lanes own genes, minors = cells; 1: lanes own cells, minors = genes
     bool wide = false;
     int64_t n_major = 0, n_minor = 0;
-    int32_t block_width = 0, n_blocks = 0, max_len = 0, n_wg = 0, row_slots = 0;
+    int32_t block_width = 0, n_blocks = 0, max_len = 0, n_wg = 0, row_slots = 0;   // block_width: the WIDEST block
     int64_t n_tasks = 0, n_slices = 0, n_slots = 0, n_segs = 0, nnz = 0;
     std::vector<uint32_t> task_major;    // n_slices * 64 ; kIdleLane pads a block's last slice
     std::vector<int32_t> slice_width;    // n_slices ; entries per lane, multiple of 4
     std::vector<int64_t> slice_off;      // n_slices ; first slot of the slice
     std::vector<int32_t> slice_block;    // n_slices ; minor block (host-side bookkeeping / tests)
     std::vector<int32_t> slice_fast;     // n_slices ; leading entries per lane that are stored ones in EVERY lane (multiple of 8)
+    std::vector<int64_t> block_start;    // n_blocks + 1 ; first minor of each block (blocks differ in width, see build_layout)
     std::vector<int32_t> seg_block;      // n_segs
     std::vector<int32_t> wg_seg0;        // n_wg + 1
     std::vector<int32_t> seg_ptr;        // n_segs + 1 : first slice of each segment
@@ -99,7 +100,8 @@ struct Layout {
 };
 
 struct LayoutParams {
-    int32_t block_width;   // minors per LDS block
+    int32_t block_width;   // minors per LDS block when the blocks are cut equal
+    int32_t block_cap;     // most minors a block may hold (LDS capacity at this rank); 0 = block_width
     int32_t max_len;       // longest task (entries), multiple of 4
     int32_t n_wg;          // persistent workgroups of the sweep kernel
     int32_t row_slots;     // 16-byte LDS slots per staged factor row at this rank (lds_row_bytes / 16)

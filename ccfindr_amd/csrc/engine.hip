@@ -48,7 +48,7 @@ struct DeviceArrays {
     uint32_t *packed = nullptr, *widx = nullptr, *task_major = nullptr, *inv_task = nullptr;
     double *wval = nullptr;
     int32_t *slice_width = nullptr, *seg_block = nullptr, *seg_ptr = nullptr, *wg_seg0 = nullptr, *inv_ptr = nullptr;
-    int32_t *slice_fast = nullptr;
+    int32_t *slice_fast = nullptr, *block_start = nullptr;
     int64_t *slice_off = nullptr;
     ~DeviceArrays()
     {
@@ -57,7 +57,7 @@ struct DeviceArrays {
         (void)hipSetDevice(device);
         (void)hipFree(packed); (void)hipFree(widx); (void)hipFree(wval); (void)hipFree(task_major); (void)hipFree(inv_task);
         (void)hipFree(slice_width); (void)hipFree(seg_block); (void)hipFree(seg_ptr); (void)hipFree(wg_seg0); (void)hipFree(inv_ptr);
-        (void)hipFree(slice_off); (void)hipFree(slice_fast);
+        (void)hipFree(slice_off); (void)hipFree(slice_fast); (void)hipFree(block_start);
         if (cur >= 0) (void)hipSetDevice(cur);
     }
 };
@@ -67,7 +67,7 @@ struct DeviceSide {
     uint32_t *packed = nullptr, *widx = nullptr, *task_major = nullptr, *inv_task = nullptr;
     double *wval = nullptr;
     int32_t *slice_width = nullptr, *seg_block = nullptr, *seg_ptr = nullptr, *wg_seg0 = nullptr, *inv_ptr = nullptr;
-    int32_t *slice_fast = nullptr;
+    int32_t *slice_fast = nullptr, *block_start = nullptr;
     int64_t *slice_off = nullptr;
     double *part = nullptr;                    // this engine's per-task partial statistics
     int64_t n_major = 0, n_minor = 0, n_tasks = 0, n_slices = 0, n_slots = 0;
@@ -177,6 +177,10 @@ int upload_side(const Layout &L, int R, int device, const vbnmf_matrix *X, Devic
         if (int rc = dev_upload(&A->slice_width, L.slice_width)) return rc;
         if (int rc = dev_upload(&A->slice_off, L.slice_off)) return rc;
         if (int rc = dev_upload(&A->slice_fast, L.slice_fast)) return rc;
+        {
+            std::vector<int32_t> bs(L.block_start.begin(), L.block_start.end());      // minors are < 2^31
+            if (int rc = dev_upload(&A->block_start, bs)) return rc;
+        }
         if (int rc = dev_upload(&A->seg_block, L.seg_block)) return rc;
         if (int rc = dev_upload(&A->seg_ptr, L.seg_ptr)) return rc;
         if (int rc = dev_upload(&A->wg_seg0, L.wg_seg0)) return rc;
@@ -187,7 +191,7 @@ int upload_side(const Layout &L, int R, int device, const vbnmf_matrix *X, Devic
     S.arrays = A;
     S.packed = A->packed; S.widx = A->widx; S.wval = A->wval; S.task_major = A->task_major; S.inv_task = A->inv_task;
     S.slice_width = A->slice_width; S.seg_block = A->seg_block; S.seg_ptr = A->seg_ptr; S.wg_seg0 = A->wg_seg0;
-    S.inv_ptr = A->inv_ptr; S.slice_off = A->slice_off; S.slice_fast = A->slice_fast;
+    S.inv_ptr = A->inv_ptr; S.slice_off = A->slice_off; S.slice_fast = A->slice_fast; S.block_start = A->block_start;
     if (int rc = dev_alloc(&S.part, (size_t)L.n_slices * kLanes * R)) return rc;
     return VBNMF_OK;
 }
@@ -202,7 +206,7 @@ SweepSide sweep_side_args(const vbnmf_engine *e, const DeviceSide &S, bool gene_
     P.llF = gene_side ? e->llw : e->llh;
     P.G = gene_side ? e->lh : e->lw;
     P.part = S.part; P.epart = epart;
-    P.n_minor = (int32_t)S.n_minor; P.block_width = S.block_width;
+    P.n_minor = (int32_t)S.n_minor; P.block_start = S.block_start;
     P.logterm = gene_side ? 1 : 0;
     P.n_wg = S.n_wg;
     P.logtab = e->logtab;

@@ -330,6 +330,7 @@ LayoutParams default_layout_params(int64_t n_major, int64_t n_minor, int R, int 
     c = (c + 7) & ~(int64_t)7;
     if (c > cmax) c = cmax;
     lp.block_width = (int32_t)c;
+    lp.block_cap = (int32_t)cmax;
     if (n_wg <= 0) n_wg = env_int("VBNMF_NWG", 256);
     if (n_wg < 1) n_wg = 1;
     lp.n_wg = n_wg;
@@ -354,7 +355,7 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
 {
     if (cb < 0 || ce > X.m || cb >= ce) return fail(VBNMF_ERR_BAD_ARG, "column range [%lld, %lld) is outside the matrix", (long long)cb, (long long)ce);
     if (lp.block_width <= 0 || lp.block_width > 65536 || lp.max_len <= 0 || lp.max_len % kWidthQuantum || lp.n_wg <= 0 || lp.row_slots <= 0 ||
-        (int64_t)lp.block_width * lp.row_slots > (int64_t)(kPackedOffsetMask >> 4) + 1)
+        (int64_t)std::max(lp.block_width, lp.block_cap) * lp.row_slots > (int64_t)(kPackedOffsetMask >> 4) + 1)
         return fail(VBNMF_ERR_BAD_ARG, "bad layout parameters");
 
     auto T0 = std::chrono::steady_clock::now();
@@ -411,14 +412,66 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
         });
         ptr = xptr.data(); idx = xidx.data(); val = xval.data();
     }
-    L.block_width = lp.block_width;
     L.max_len = lp.max_len;
     L.n_wg = lp.n_wg;
     L.row_slots = lp.row_slots;
     const int64_t nmaj = L.n_major;
-    const int32_t C = L.block_width;
-    const int32_t nblk = (int32_t)((L.n_minor + C - 1) / C);
+    // Minor blocks.  Whole workgroups are handed to blocks (a workgroup stages ONE block per side), so a block whose
+    // cost is 9.8 workgroups' worth gets 10 or 9 of them -- and in the second case each of its workgroups carries 9 %
+    // more than the rest (measured on the headline matrix, gene side: 26 equal blocks, 22 with 10 workgroups and 4
+    // with 9: modelled cost max / mean 1.13, and the slowest workgroups took 100 us against a mean of 88).  The block
+    // boundaries are therefore put where the cumulative entry count reaches a whole number of workgroup quotas:
+    // every block is worth an integer G_b of them (G_b as equal as possible), no wider than the LDS allows.
+    // With more blocks than workgroups (huge matrices) the blocks stay equal and are bin-packed below.
+    const int32_t wmax = lp.block_cap > 0 ? lp.block_cap : lp.block_width;
+    std::vector<int64_t> bstart;
+    {
+        std::vector<int64_t> mcount(L.n_minor + 1, 0);                     // entries per minor -> prefix sums
+        {
+            const int T = host_threads();
+            std::vector<std::vector<int64_t>> part(T);
+            parallel_for(nmaj, [&](int64_t b, int64_t e, int tid) {
+                std::vector<int64_t> &c = part[tid];
+                c.assign(L.n_minor, 0);
+                for (int64_t q = ptr[b]; q < ptr[e]; q++) c[idx[q]]++;
+            }, T);
+            for (const auto &c : part)
+                if (!c.empty()) for (int64_t j = 0; j < L.n_minor; j++) mcount[j + 1] += c[j];
+        }
+        for (int64_t j = 0; j < L.n_minor; j++) mcount[j + 1] += mcount[j];
+        const int64_t total = mcount[L.n_minor];
+        int64_t nb = (L.n_minor + wmax - 1) / wmax;
+        const bool proportional = env_int("VBNMF_EQUAL_BLOCKS", 0) == 0 && total > 0;
+        for (; proportional && nb <= lp.n_wg; nb++) {
+            std::vector<int64_t> cand(nb + 1, 0);
+            bool ok = true;
+            int64_t gsum = 0;
+            for (int64_t b = 0; b < nb && ok; b++) {
+                gsum += lp.n_wg / nb + (b < lp.n_wg % nb ? 1 : 0);              // G_b: as equal as possible
+                int64_t end = L.n_minor;
+                if (b + 1 < nb) {
+                    const double target = (double)total * (double)gsum / (double)lp.n_wg;
+                    end = std::lower_bound(mcount.begin(), mcount.end(), (int64_t)std::llround(target)) - mcount.begin();
+                    end = std::min<int64_t>(std::max<int64_t>(end, cand[b] + 1), L.n_minor - (nb - 1 - b));
+                }
+                cand[b + 1] = end;
+                ok = end - cand[b] <= wmax;
+            }
+            if (ok) { bstart.swap(cand); break; }
+        }
+        if (bstart.empty()) {                                                   // equal blocks
+            nb = (L.n_minor + lp.block_width - 1) / lp.block_width;
+            bstart.resize(nb + 1);
+            for (int64_t b = 0; b <= nb; b++) bstart[b] = std::min<int64_t>(L.n_minor, b * (int64_t)lp.block_width);
+        }
+    }
+    const int32_t nblk = (int32_t)bstart.size() - 1;
     L.n_blocks = nblk;
+    L.block_start.assign(bstart.begin(), bstart.end());
+    int32_t widest = 0;
+    for (int32_t b = 0; b < nblk; b++) widest = std::max<int32_t>(widest, (int32_t)(bstart[b + 1] - bstart[b]));
+    L.block_width = widest;                                                     // what the LDS image is sized for
+    lap("blocks");
 
     // bpos[major][b] = position of the major's first entry whose minor is in block >= b
     std::vector<int64_t> bpos((size_t)nmaj * (nblk + 1));
@@ -427,7 +480,7 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
             int64_t q = ptr[M], t = ptr[M + 1];
             int64_t *bp = &bpos[(size_t)M * (nblk + 1)];
             for (int32_t blk = 0; blk <= nblk; blk++) {
-                int64_t lim = (int64_t)blk * C;
+                int64_t lim = bstart[blk];
                 while (q < t && idx[q] < lim) q++;
                 bp[blk] = q;
             }
@@ -587,10 +640,20 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
                 const int g = G[blk];
                 const int64_t s0 = bslice0[blk], s1 = bslice0[blk + 1];
                 for (int j = 0; j < g; j++) shares[w + j].emplace_back(blk, std::vector<int32_t>());
-                for (int64_t i = s0; i < s1; i++) {            // slices are in descending width order: snake deal
-                    int64_t k = i - s0, round = k / g, pos = k % g;
-                    int j = (round & 1) ? (int)(g - 1 - pos) : (int)pos;
-                    shares[w + j].back().second.push_back((int32_t)i);
+                {
+                    // longest-processing-time deal: slices by cost, descending (ties by id), each to the workgroup
+                    // of the block with the least cost so far (ties to the lowest) -- equal cost AND, because the
+                    // costly slices go round first, the same mix of long and short slices in every share
+                    std::vector<int32_t> by_cost;
+                    for (int64_t i = s0; i < s1; i++) by_cost.push_back((int32_t)i);
+                    std::stable_sort(by_cost.begin(), by_cost.end(), [&](int32_t x, int32_t y) { return cost(x) > cost(y); });
+                    std::vector<double> load(g, 0.0);
+                    for (int32_t i : by_cost) {
+                        int j = 0;
+                        for (int q = 1; q < g; q++) if (load[q] < load[j]) j = q;
+                        shares[w + j].back().second.push_back(i);
+                        load[j] += cost(i);
+                    }
                 }
                 w += g;
             }
@@ -683,7 +746,7 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
         // first, see above), phase 1 = the others (every entry when the fast stretch is off)
         std::vector<int32_t> bucket[2][16][16];
         for (int64_t s = b; s < e; s++) {
-            const int32_t m0 = L.slice_block[s] * C;
+            const int32_t m0 = (int32_t)bstart[L.slice_block[s]];
             const int64_t so = L.slice_off[s];
             auto put = [&](int lane, int64_t t, int64_t q) {
                 int64_t slot = so + (t / kUnroll) * (kLanes * kUnroll) + lane * kUnroll + (t % kUnroll);
@@ -778,7 +841,7 @@ std::shared_ptr<const Layout> shared_layout(const vbnmf_matrix *X, int side, con
     const int cap = 2 * std::max(0, env_int("VBNMF_LAYOUT_CACHE", 3));       // entries = pairs x 2 sides
     LayoutCache &C = X->layouts;
     auto same = [&](const LayoutCache::Entry &q) {
-        return q.side == side && q.lp.block_width == lp.block_width && q.lp.max_len == lp.max_len && q.lp.n_wg == lp.n_wg &&
+        return q.side == side && q.lp.block_width == lp.block_width && q.lp.block_cap == lp.block_cap && q.lp.max_len == lp.max_len && q.lp.n_wg == lp.n_wg &&
                q.lp.row_slots == lp.row_slots;
     };
     {
@@ -951,7 +1014,7 @@ int vbnmf_layout_build(const vbnmf_matrix *X, int64_t col_begin, int64_t col_end
     view->task_major = L.task_major.data(); view->slice_width = L.slice_width.data();
     view->slice_off = L.slice_off.data(); view->slice_block = L.slice_block.data(); view->slice_fast = L.slice_fast.data();
     view->seg_block = L.seg_block.data(); view->wg_seg0 = L.wg_seg0.data();
-    view->seg_ptr = L.seg_ptr.data(); view->row_slots = L.row_slots;
+    view->seg_ptr = L.seg_ptr.data(); view->row_slots = L.row_slots; view->block_start = L.block_start.data();
     view->inv_ptr = L.inv_ptr.data(); view->inv_task = L.inv_task.data();
     view->packed = L.wide ? nullptr : L.packed.data();
     view->wide_idx = L.wide ? L.wide_idx.data() : nullptr;

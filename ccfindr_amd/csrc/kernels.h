@@ -45,6 +45,7 @@ struct SweepSide {
     const int32_t *slice_fast;     // [n_slices] leading entries per lane that are stored ones in every lane (multiple of 8)
     const int64_t *slice_off;      // [n_slices]
     const int32_t *seg_block;      // [n_segs]
+    const int32_t *block_start;    // [n_blocks + 1] first minor of each block
     const int32_t *wg_seg0;        // [n_wg + 1]
     const int32_t *seg_ptr;        // [n_segs + 1] first slice of each segment (slices are numbered in processing order)
     const double *F;               // [n_major][R]  factor owned by the lanes
@@ -53,7 +54,6 @@ struct SweepSide {
     double *part;                  // [n_slices*64][R] partial statistics per task
     double *epart;                 // [n_wg] evidence partials, one per workgroup
     int32_t n_minor;
-    int32_t block_width;
     int32_t logterm;               // this side also accumulates sum x*log(wth)
     int32_t n_wg;
     const LogTabEntry *logtab;     // [128] ln table (staged at the front of LDS)
@@ -222,8 +222,8 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
     int *ticket = reinterpret_cast<int *>(reinterpret_cast<char *>(ldsG) + kLdsCtrBase);
     for (int seg = seg0; seg < seg1; seg++) {
         const int blk = S.seg_block[seg];
-        const int m0 = blk * S.block_width;
-        const int cw = min(S.block_width, S.n_minor - m0);
+        const int m0 = S.block_start[blk];
+        const int cw = S.block_start[blk + 1] - m0;
         __syncthreads();                                   // readers of the previous block are done
         if (threadIdx.x == 0) *ticket = 0;
         {

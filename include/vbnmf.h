@@ -344,7 +344,7 @@ typedef struct {
     int32_t side, wide;            /* wide: 0 = 4-byte entries (integer counts; one above 16383 takes several slots of the
                                       same minor), 1 = u32 index + f64 value (non-integer X) */
     int64_t n_major, n_minor;      /* lanes own majors; minors are gathered from LDS */
-    int32_t block_width;           /* minors per LDS block */
+    int32_t block_width;           /* minors in the widest LDS block (blocks differ: see block_start) */
     int32_t n_blocks;              /* ceil(n_minor / block_width) */
     int32_t max_len;               /* longest task (entries per lane) */
     int32_t n_wg;                  /* persistent workgroups the work list is cut for */
@@ -360,6 +360,8 @@ typedef struct {
     const int32_t *slice_fast;     /* [n_slices] leading entries per lane that are stored ones (value exactly 1) in EVERY
                                       lane of the slice (multiple of 8; 0 for wide layouts): the sweep runs them through
                                       a shorter loop.  A task's ones come first, its other entries after them. */
+    const int64_t *block_start;    /* [n_blocks+1] first minor of each block: boundaries sit where the cumulative entry
+                                      count reaches a whole number of workgroup quotas */
     const int32_t *seg_block;      /* [n_segs] */
     const int32_t *wg_seg0;        /* [n_wg+1] segments of each workgroup */
     const int32_t *seg_ptr;        /* [n_segs+1] first slice of each segment; slices are numbered in processing order */

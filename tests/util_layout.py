@@ -23,6 +23,7 @@ def build_layout(M, side, r, cols=None):
         out["slice_block"] = arr(v.slice_block, v.n_slices)
         out["slice_fast"] = arr(v.slice_fast, v.n_slices)
         out["seg_block"] = arr(v.seg_block, v.n_segs)
+        out["block_start"] = arr(v.block_start, v.n_blocks + 1)
         out["seg_ptr"] = arr(v.seg_ptr, v.n_segs + 1)
         out["wg_seg0"] = arr(v.wg_seg0, v.n_wg + 1)
         out["inv_ptr"] = arr(v.inv_ptr, v.n_major + 1)
@@ -42,7 +43,9 @@ def reconstruct(view):
     A = np.zeros((view["n_major"], view["n_minor"]))
     nslot = np.zeros(A.shape, dtype=np.int64)          # slots per (major, minor)
     npart = np.zeros(A.shape, dtype=np.int64)          # ... of which not a full 16383 piece
-    C = view["block_width"]
+    bstart = view["block_start"]
+    assert bstart[0] == 0 and bstart[-1] == view["n_minor"] and np.all(np.diff(bstart) > 0)
+    assert np.max(np.diff(bstart)) == view["block_width"]          # block_width = the widest block (what the LDS is sized for)
     ntask = 0
     first_minor = {}
     for s in range(view["n_slices"]):
@@ -71,8 +74,8 @@ def reconstruct(view):
             n_live = int(live.sum())
             assert n_live >= 1 and live[:n_live].all()        # entries first, padding only at the tail
             assert (idx[~live] == 0).all()
-            cols = blk * C + idx[live]
-            assert (cols < min((blk + 1) * C, view["n_minor"])).all()
+            cols = bstart[blk] + idx[live]
+            assert (cols < bstart[blk + 1]).all()
             # any order (bank-conflict schedule).  A (major, minor) pair occupies one slot, unless a count above the
             # packed range was split: then all but one of its slots hold a full piece (16383) -- checked at the end.
             np.add.at(A, (np.full(cols.size, M), cols), val[live])
