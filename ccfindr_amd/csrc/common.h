@@ -118,15 +118,19 @@ constexpr int kLdsReserveBytes = 4112;
 // Threads per workgroup of the sweep kernel at padded rank R: as many waves per SIMD as the
 // kernel's register need (factor row + accumulators + two gathered rows, ~14 R + 20 VGPRs) allows
 // without spilling: 4 waves/SIMD up to R = 4, 3 up to 14 (measured on the C3 matrix, round 2: 768 against 512 threads
-// 0.220 / 0.225 ms at rank 12, 0.250 / 0.253 at 14, 0.309 / 0.303 at 16), 2 up to 26, 1 beyond (spills at 2 waves
-// made R = 32 ten times slower).
+// 0.220 / 0.225 ms at rank 12, 0.250 / 0.253 at 14, 0.309 / 0.303 at 16), 2 beyond.  From R = 28 on the loop keeps ONE
+// gathered-row buffer (factor row + accumulators + one row = 6 R VGPRs; two rows spill at 2 waves), which also fits 2
+// waves per SIMD: sweep 0.762 -> 0.695 ms at rank 28 and 1.132 -> 0.873 ms at rank 32 against 1 wave (C3 matrix).
 #ifndef VBNMF_T768_UPTO
 #define VBNMF_T768_UPTO 14          // largest padded rank run with 768 threads (3 waves / SIMD); experiments override it
 #endif
 #ifndef VBNMF_ONEBUF_FROM
-#define VBNMF_ONEBUF_FROM 30        // smallest padded rank whose sweep keeps ONE gathered-row buffer (no LDS look-ahead)
+#define VBNMF_ONEBUF_FROM 28        // smallest padded rank whose sweep keeps ONE gathered-row buffer (no LDS look-ahead)
 #endif
-constexpr int sweep_threads(int R) { return R <= 4 ? 1024 : (R <= VBNMF_T768_UPTO ? 768 : (R <= 26 ? 512 : 256)); }
+#ifndef VBNMF_T512_UPTO
+#define VBNMF_T512_UPTO 32          // largest padded rank run with 512 threads (2 waves / SIMD)
+#endif
+constexpr int sweep_threads(int R) { return R <= 4 ? 1024 : (R <= VBNMF_T768_UPTO ? 768 : (R <= VBNMF_T512_UPTO ? 512 : 256)); }
 // Default block width / task length for a side at padded rank R with `nnz` stored entries (0: unknown, longest
 // tasks); n_wg <= 0 picks the default (256).
 LayoutParams default_layout_params(int64_t n_major, int64_t n_minor, int R, int n_wg = 0, int64_t nnz = 0);
