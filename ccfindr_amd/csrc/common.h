@@ -130,7 +130,13 @@ constexpr int kLdsReserveBytes = 4112;
 #ifndef VBNMF_T512_UPTO
 #define VBNMF_T512_UPTO 32          // largest padded rank run with 512 threads (2 waves / SIMD)
 #endif
-constexpr int sweep_threads(int R) { return R <= 4 ? 1024 : (R <= VBNMF_T768_UPTO ? 768 : (R <= VBNMF_T512_UPTO ? 512 : 256)); }
+#ifndef VBNMF_T1024_UPTO
+#define VBNMF_T1024_UPTO 4          // largest padded rank run with 1024 threads (4 waves / SIMD)
+#endif
+#ifndef VBNMF_ONEBUF_UPTO
+#define VBNMF_ONEBUF_UPTO 0         // experiments: padded ranks <= this ALSO use the one-buffer loop
+#endif
+constexpr int sweep_threads(int R) { return R <= VBNMF_T1024_UPTO ? 1024 : (R <= VBNMF_T768_UPTO ? 768 : (R <= VBNMF_T512_UPTO ? 512 : 256)); }
 // Default block width / task length for a side at padded rank R with `nnz` stored entries (0: unknown, longest
 // tasks); n_wg <= 0 picks the default (256).
 LayoutParams default_layout_params(int64_t n_major, int64_t n_minor, int R, int n_wg = 0, int64_t nnz = 0);

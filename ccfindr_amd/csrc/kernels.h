@@ -270,7 +270,7 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
             // next trip issued before this trip's arithmetic, LDS rows fetched one entry ahead.
             const int np = ng >> 1;
             double2 g0[R / 2];
-            if (R >= VBNMF_ONEBUF_FROM && !WIDE) {
+            if ((R >= VBNMF_ONEBUF_FROM || R <= VBNMF_ONEBUF_UPTO) && !WIDE) {
                 // very large ranks: the factor row, the accumulators and ONE gathered row already fill
                 // the register file, so no second row buffer and no look-ahead here
                 const uint4 *E = reinterpret_cast<const uint4 *>(S.packed + off) + lane;
