@@ -6,7 +6,7 @@ CSRC := ccfindr_amd/csrc
 LIB := ccfindr_amd/lib/libvbnmf_hip.so
 HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -ffp-contract=off -Wall -Wno-unused-function
 SRCS := $(CSRC)/host.cpp $(CSRC)/mtx.cpp $(CSRC)/engine.hip
-HDRS := $(CSRC)/common.h $(CSRC)/kernels.h $(CSRC)/mlnmf.h $(CSRC)/special.h include/vbnmf.h
+HDRS := $(CSRC)/common.h $(CSRC)/kernels.h $(CSRC)/mlnmf.h $(CSRC)/special.h $(CSRC)/init.h $(CSRC)/comm.h include/vbnmf.h
 
 all: $(LIB) oracle
 
