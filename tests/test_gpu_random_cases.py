@@ -65,3 +65,62 @@ def test_ml_step_random_case(seed):
     wh = want["ew"] @ want["eh"]
     scale = (np.abs(X * np.log(wh)).sum() + wh.sum()) / n / m
     assert abs(got["lk"] - lk) <= 1e-11 * scale, (seed, got["lk"], lk, scale)
+
+
+def _counts(kind, n, m, seed):
+    rng = np.random.default_rng(seed)
+    if kind == "all_ones":                  # binary matrix: every stored value is 1 -> the whole slice is the leading stretch
+        X = (rng.random((n, m)) < 0.25).astype(np.float64)
+    elif kind == "no_ones":                 # every stored value >= 2 -> the stretch is empty everywhere
+        X = rng.poisson(0.4, size=(n, m)).astype(np.float64)
+        X[X > 0] += 1.0
+    elif kind == "ones_then_big":           # mostly ones with a heavy tail: stretches of very different length per task
+        X = (rng.random((n, m)) < 0.3).astype(np.float64)
+        big = rng.random((n, m)) < 0.03
+        X[big] = rng.integers(2, 60, size=int(big.sum())).astype(np.float64)
+    else:                                   # "mixed": counts 0..3, about half of the stored ones are ones
+        X = rng.poisson(0.8, size=(n, m)).astype(np.float64)
+    X[np.arange(n), rng.integers(0, m, n)] += 1.0
+    X[rng.integers(0, n, m), np.arange(m)] += 1.0
+    return np.asfortranarray(X)
+
+
+@pytest.mark.parametrize("kind", ["all_ones", "no_ones", "ones_then_big", "mixed"])
+@pytest.mark.parametrize("r", [3, 10, 16, 28, 30])
+def test_leading_ones_stretch_against_the_oracle(kind, r):
+    """The sweep's shorter loop over a slice's leading stored ones (layout slice_fast; deferred logarithm through a
+    running product on the gene side) against the dense literal oracle, for matrices where that stretch is everything,
+    nothing, or ragged; the ranks cover the pipelined two-buffer loop at 1024 / 768 / 512 threads and the one-buffer
+    loop (padded rank >= 28).  Three resident steps, so the evidence of the running-product form enters the test."""
+    import ccfindr_amd as C
+    from ccfindr_amd import synth
+    from oracle import vbnmf_oracle as O
+    n, m = 700, 1100
+    X = _counts(kind, n, m, seed=len(kind) * 100 + r)
+    hy = {"aw": 1.0, "bw": 1.0, "ah": 1.0, "bh": 1.0}
+    wh = synth.random_state(n, m, r, hy, seed=r)
+    eng = C.VBEngine(C.CountMatrix(X), r)
+    eng.set_state(wh["lw"], wh["lh"], wh["eh"])
+    ref = wh
+    for _ in range(3):
+        lkh, _ = eng.step(hy)
+        ref = O.update_dense(X, ref, hy, C.EPS)
+        assert abs(lkh / ref["lkh"] - 1) <= 1e-10, (kind, r, lkh, ref["lkh"])
+    got = eng.get_state()
+    eng.close()
+    for k in ("lw", "lh", "ew", "eh", "dw", "dh"):
+        assert relerr(got[k], ref[k]) <= 1e-11, (kind, r, k, relerr(got[k], ref[k]))
+
+
+def test_leading_ones_stretch_is_recorded_by_the_layout():
+    """slice_fast of a binary matrix covers every full 8-entry trip of every full slice (CPU-side view of the layout)."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import ccfindr_amd as C
+    from util_layout import build_layout
+    X = _counts("all_ones", 300, 500, seed=1)
+    X[X > 1] = 1.0
+    v = build_layout(C.CountMatrix(X), 0, 10)
+    assert v["slice_fast"].sum() > 0.5 * v["slice_width"].sum()
+    v = build_layout(C.CountMatrix(_counts("no_ones", 300, 500, seed=2) + 0.0), 0, 10)
+    assert v["slice_fast"].sum() <= 0.05 * v["slice_width"].sum()
