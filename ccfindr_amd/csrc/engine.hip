@@ -1801,18 +1801,152 @@ int vbnmf_test_special_device(int32_t kind, int64_t n, const double *x, double *
 }
 
 // ---------------------------------------------------------------- stateless forms
-static int update_once(vbnmf_matrix *X, int32_t r, const double *lw_in, const double *lh_in, const double *eh_in,
-                       double aw, double bw, double ah, double bh, double fudge,
-                       double *lw, double *lh, double *ew, double *eh, double *dw, double *dh, double *lkh)
-{
+}  // extern "C"
+
+namespace {
+
+// The reference's caller hands the SAME X to every one of its thousands of calls (R/bayesian.R:339).  The stateless
+// entries therefore keep the last ingested matrix and its engine alive, keyed by the CONTENT of X (dimensions + a
+// 64-bit hash of every byte of the arrays handed in, formed by all host threads): a call with an X seen before costs
+// the hash, the state upload, one step and the state download instead of ingestion + two layouts + an engine.
+// VBNMF_STATELESS_CACHE=0 turns it off; vbnmf_stateless_cache_clear() releases what is held.
+struct StatelessCache {
+    std::mutex mu;                    // held for the whole call: stateless calls are serialised
+    bool valid = false;
+    int kind = 0;                     // 0 dense, 1 csc
+    int64_t n = 0, m = 0, nnz = 0;
+    uint64_t hash = 0;
+    vbnmf_matrix *X = nullptr;
     vbnmf_engine *e = nullptr;
-    int rc = vbnmf_engine_create(X, r, 0, &e);
-    if (!rc) rc = vbnmf_engine_set_state(e, lw_in, lh_in, eh_in);
+    int r = 0;
+    void drop()
+    {
+        vbnmf_engine_destroy(e); e = nullptr;
+        vbnmf_matrix_destroy(X); X = nullptr;
+        valid = false;
+    }
+};
+StatelessCache &stateless_cache() { static StatelessCache c; return c; }
+
+uint64_t hash_bytes(const void *data, size_t bytes, uint64_t seed)
+{
+    // per-chunk multiply-xorshift over 8-byte words, chunks combined in order: independent of the thread count
+    const size_t chunk = (size_t)1 << 22;
+    const size_t nchunks = (bytes + chunk - 1) / chunk;
+    std::vector<uint64_t> part(nchunks ? nchunks : 1, 0);
+    const unsigned char *p = static_cast<const unsigned char *>(data);
+    parallel_for((int64_t)nchunks, [&](int64_t b, int64_t e, int) {
+        for (int64_t c = b; c < e; c++) {
+            const size_t o = (size_t)c * chunk, len = std::min(chunk, bytes - o);
+            uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)c;
+            size_t q = 0;
+            for (; q + 8 <= len; q += 8) {
+                uint64_t w;
+                std::memcpy(&w, p + o + q, 8);
+                h = (h ^ w) * 0xFF51AFD7ED558CCDull;
+                h ^= h >> 32;
+            }
+            for (; q < len; q++) { h = (h ^ p[o + q]) * 0x100000001B3ull; }
+            part[c] = h;
+        }
+    });
+    uint64_t h = seed;
+    for (uint64_t v : part) { h = (h ^ v) * 0xC4CEB9FE1A85EC53ull; h ^= h >> 29; }
+    return h;
+}
+
+bool stateless_cache_enabled()
+{
+    const char *sv = getenv("VBNMF_STATELESS_CACHE");
+    return !(sv && sv[0] == '0');
+}
+
+// The engine of rank r on the matrix with this key: from the cache, or ingested now through `ingest`.
+int stateless_engine(int kind, int64_t n, int64_t m, int64_t nnz, uint64_t hash, int32_t r,
+                     const std::function<int(vbnmf_matrix **)> &ingest, vbnmf_engine **out)
+{
+    StatelessCache &C = stateless_cache();
+    const bool hit = C.valid && C.kind == kind && C.n == n && C.m == m && C.nnz == nnz && C.hash == hash;
+    if (!hit) {
+        C.drop();
+        if (int rc = ingest(&C.X)) { C.X = nullptr; return rc; }
+        C.kind = kind; C.n = n; C.m = m; C.nnz = nnz; C.hash = hash; C.valid = true;
+    }
+    if (!C.e || C.r != r) {
+        vbnmf_engine_destroy(C.e); C.e = nullptr;
+        if (int rc = vbnmf_engine_create(C.X, r, 0, &C.e)) { C.e = nullptr; return rc; }
+        C.r = r;
+    }
+    *out = C.e;
+    return VBNMF_OK;
+}
+
+int update_once(vbnmf_engine *e, const double *lw_in, const double *lh_in, const double *eh_in,
+                double aw, double bw, double ah, double bh, double fudge,
+                double *lw, double *lh, double *ew, double *eh, double *dw, double *dh, double *lkh)
+{
+    int rc = vbnmf_engine_set_state(e, lw_in, lh_in, eh_in);
     if (!rc) rc = vbnmf_engine_step(e, aw, bw, ah, bh, fudge, lkh, nullptr);
     if (!rc) rc = vbnmf_engine_get_state(e, lw, lh, ew, eh, dw, dh);
-    vbnmf_engine_destroy(e);
-    vbnmf_matrix_destroy(X);
     return rc;
+}
+
+int ml_update_once(vbnmf_engine *e, const double *w_in, const double *h_in, int32_t prior, double gamma_a, double gamma_b,
+                   double *w, double *h, double *lk)
+{
+    int rc = vbnmf_engine_ml_set_state(e, w_in, h_in);
+    if (!rc) rc = vbnmf_engine_ml_step(e, prior, gamma_a, gamma_b, lk);
+    if (!rc) rc = vbnmf_engine_ml_get_state(e, w, h);
+    return rc;
+}
+
+// dense / CSC front ends shared by the VB and ML stateless calls: `use(engine)` runs under the cache's lock
+int with_dense(int64_t n, int64_t m, int32_t r, const double *X, const std::function<int(vbnmf_engine *)> &use)
+{
+    if (n <= 0 || m <= 0 || !X) return fail(VBNMF_ERR_BAD_ARG, "X is NULL or has a non-positive dimension");
+    StatelessCache &C = stateless_cache();
+    std::lock_guard<std::mutex> g(C.mu);
+    const bool cache = stateless_cache_enabled();
+    const uint64_t h = cache ? hash_bytes(X, (size_t)n * (size_t)m * sizeof(double), 0x64656E7365ull) : 0;
+    if (!cache) C.drop();
+    vbnmf_engine *e = nullptr;
+    int rc = stateless_engine(0, n, m, 0, h, r, [&](vbnmf_matrix **M) { return vbnmf_matrix_from_dense(n, m, X, M); }, &e);
+    if (!rc) rc = use(e);
+    if (!cache || rc) C.drop();
+    return rc;
+}
+
+int with_csc(int64_t n, int64_t m, int32_t r, const int32_t *p, const int32_t *i, const double *x,
+             const std::function<int(vbnmf_engine *)> &use)
+{
+    if (n <= 0 || m <= 0 || !p) return fail(VBNMF_ERR_BAD_ARG, "a CSC slot pointer is NULL or a dimension is non-positive");
+    StatelessCache &C = stateless_cache();
+    std::lock_guard<std::mutex> g(C.mu);
+    const bool cache = stateless_cache_enabled();
+    const int64_t nnz = p[m];
+    uint64_t h = 0;
+    if (cache && nnz >= 0 && (nnz == 0 || (i && x))) {
+        h = hash_bytes(p, (size_t)(m + 1) * sizeof(int32_t), 0x637363ull);
+        h = hash_bytes(i, (size_t)nnz * sizeof(int32_t), h);
+        h = hash_bytes(x, (size_t)nnz * sizeof(double), h);
+    }
+    if (!cache) C.drop();
+    vbnmf_engine *e = nullptr;
+    int rc = stateless_engine(1, n, m, nnz, h, r, [&](vbnmf_matrix **M) { return vbnmf_matrix_from_csc(n, m, p, i, x, M); }, &e);
+    if (!rc) rc = use(e);
+    if (!cache || rc) C.drop();
+    return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+void vbnmf_stateless_cache_clear(void)
+{
+    StatelessCache &C = stateless_cache();
+    std::lock_guard<std::mutex> g(C.mu);
+    C.drop();
 }
 
 int vbnmf_update_dense(int64_t n, int64_t m, int32_t r, const double *X, const double *lw_in, const double *lh_in,
@@ -1820,9 +1954,8 @@ int vbnmf_update_dense(int64_t n, int64_t m, int32_t r, const double *X, const d
                        double *lw, double *lh, double *ew, double *eh, double *dw, double *dh, double *lkh)
 {
     if (!lw_in || !lh_in || !eh_in) return fail(VBNMF_ERR_BAD_ARG, "a wh member is NULL");
-    vbnmf_matrix *M = nullptr;
-    if (int rc = vbnmf_matrix_from_dense(n, m, X, &M)) return rc;
-    return update_once(M, r, lw_in, lh_in, eh_in, aw, bw, ah, bh, fudge, lw, lh, ew, eh, dw, dh, lkh);
+    return with_dense(n, m, r, X, [&](vbnmf_engine *e) {
+        return update_once(e, lw_in, lh_in, eh_in, aw, bw, ah, bh, fudge, lw, lh, ew, eh, dw, dh, lkh); });
 }
 
 int vbnmf_update_csc(int64_t n, int64_t m, int32_t r, const int32_t *p, const int32_t *i, const double *x,
@@ -1831,31 +1964,15 @@ int vbnmf_update_csc(int64_t n, int64_t m, int32_t r, const int32_t *p, const in
                      double *lw, double *lh, double *ew, double *eh, double *dw, double *dh, double *lkh)
 {
     if (!lw_in || !lh_in || !eh_in) return fail(VBNMF_ERR_BAD_ARG, "a wh member is NULL");
-    vbnmf_matrix *M = nullptr;
-    if (int rc = vbnmf_matrix_from_csc(n, m, p, i, x, &M)) return rc;
-    return update_once(M, r, lw_in, lh_in, eh_in, aw, bw, ah, bh, fudge, lw, lh, ew, eh, dw, dh, lkh);
-}
-
-static int ml_update_once(vbnmf_matrix *X, int32_t r, const double *w_in, const double *h_in, int32_t prior,
-                          double gamma_a, double gamma_b, double *w, double *h, double *lk)
-{
-    vbnmf_engine *e = nullptr;
-    int rc = vbnmf_engine_create(X, r, 0, &e);
-    if (!rc) rc = vbnmf_engine_ml_set_state(e, w_in, h_in);
-    if (!rc) rc = vbnmf_engine_ml_step(e, prior, gamma_a, gamma_b, lk);
-    if (!rc) rc = vbnmf_engine_ml_get_state(e, w, h);
-    vbnmf_engine_destroy(e);
-    vbnmf_matrix_destroy(X);
-    return rc;
+    return with_csc(n, m, r, p, i, x, [&](vbnmf_engine *e) {
+        return update_once(e, lw_in, lh_in, eh_in, aw, bw, ah, bh, fudge, lw, lh, ew, eh, dw, dh, lkh); });
 }
 
 int vbnmf_ml_update_dense(int64_t n, int64_t m, int32_t r, const double *X, const double *w_in, const double *h_in,
                           int32_t prior, double gamma_a, double gamma_b, double *w, double *h, double *lk)
 {
     if (!w_in || !h_in) return fail(VBNMF_ERR_BAD_ARG, "w or h is NULL");
-    vbnmf_matrix *M = nullptr;
-    if (int rc = vbnmf_matrix_from_dense(n, m, X, &M)) return rc;
-    return ml_update_once(M, r, w_in, h_in, prior, gamma_a, gamma_b, w, h, lk);
+    return with_dense(n, m, r, X, [&](vbnmf_engine *e) { return ml_update_once(e, w_in, h_in, prior, gamma_a, gamma_b, w, h, lk); });
 }
 
 int vbnmf_ml_update_csc(int64_t n, int64_t m, int32_t r, const int32_t *p, const int32_t *i, const double *x,
@@ -1863,9 +1980,7 @@ int vbnmf_ml_update_csc(int64_t n, int64_t m, int32_t r, const int32_t *p, const
                         double *w, double *h, double *lk)
 {
     if (!w_in || !h_in) return fail(VBNMF_ERR_BAD_ARG, "w or h is NULL");
-    vbnmf_matrix *M = nullptr;
-    if (int rc = vbnmf_matrix_from_csc(n, m, p, i, x, &M)) return rc;
-    return ml_update_once(M, r, w_in, h_in, prior, gamma_a, gamma_b, w, h, lk);
+    return with_csc(n, m, r, p, i, x, [&](vbnmf_engine *e) { return ml_update_once(e, w_in, h_in, prior, gamma_a, gamma_b, w, h, lk); });
 }
 
 }  // extern "C"

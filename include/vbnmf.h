@@ -245,6 +245,12 @@ int vbnmf_update_dense(int64_t n, int64_t m, int32_t r, const double *X,
                        double aw, double bw, double ah, double bh, double fudge,
                        double *lw, double *lh, double *ew, double *eh,
                        double *dw, double *dh, double *lkh);
+/* The stateless entries (these two and vbnmf_ml_update_*) keep the LAST ingested matrix and its engine alive between
+ * calls, keyed by the content of X (dimensions + a 64-bit hash of every byte handed in): the reference's loop passes
+ * the same X thousands of times (R/bayesian.R:339), and a repeat then costs the hash, the state transfer and one step
+ * instead of ingestion + layouts + engine.  Results do not depend on it.  VBNMF_STATELESS_CACHE=0 disables it;
+ * vbnmf_stateless_cache_clear() releases what is held (device and host memory). */
+void vbnmf_stateless_cache_clear(void);
 /* Same with X as dgCMatrix slots (no densification on the R side). */
 int vbnmf_update_csc(int64_t n, int64_t m, int32_t r, const int32_t *p, const int32_t *i,
                      const double *x,
