@@ -480,6 +480,19 @@ __device__ __forceinline__ void bp_colsums(const double *__restrict__ bp, int nb
     }
 }
 
+// The same for two tables at once: the loads of both are in flight together (one memory latency instead of two).
+__device__ __forceinline__ void bp_colsums2(const double *__restrict__ bpA, const double *__restrict__ bpB, int nb, int ncol,
+                                            double *outA, double *outB, int nthreads)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = nthreads >> 6;
+    for (int c = wave; c < ncol; c += nw) {
+        double sa = 0.0, sb = 0.0;
+        for (int b = lane; b < nb; b += 64) { sa += bpA[(size_t)b * ncol + c]; sb += bpB[(size_t)b * ncol + c]; }
+        sa = wave_sum(sa); sb = wave_sum(sb);
+        if (lane == 0) { outA[c] = sa; outB[c] = sb; }
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // Posterior update of one factor (both sides share it).  256 persistent blocks; thread
 // (row_sub, k) walks its block's majors with a fixed k.
@@ -517,17 +530,21 @@ __global__ __launch_bounds__(kUpdateThreads) void k_update(
     constexpr int RB = kUpdateThreads / R;       // majors per pass
     __shared__ double s_other[R + 2];
     __shared__ double s_e[kUpdateThreads], s_t[kUpdateThreads], s_l[kUpdateThreads];
+    int stopped = 0;
     if (ctl) {                                   // device-driven loop: hyper-parameters come from the control block
-        if (ctl->stop) return;
+        stopped = ctl->stop;                     // (tested below: these loads and the column sums' travel together)
         a = ctl->hyper[2 * side]; b = ctl->hyper[2 * side + 1];
-        double psi_a, lg_a;
-        dev_psi_lgamma(a, &psi_a, &lg_a);
-        lga = -lg_a + a * log(a / b);            // reference src/vbnmf_update.cpp:82 / :87
     }
     const int t = threadIdx.x;
     if (other_nb > 0) bp_colsums(other_bp, other_nb, R + 2, s_other, kUpdateThreads);
     else if (t < R) s_other[t] = other[t];
+    if (stopped) return;
     __syncthreads();
+    if (ctl) {
+        double psi_a, lg_a;
+        dev_psi_lgamma(a, &psi_a, &lg_a);
+        lga = -lg_a + a * log(a / b);            // reference src/vbnmf_update.cpp:82 / :87
+    }
 
     const int row = t / R, k = t - row * R;
     const int64_t per = (nmaj + gridDim.x - 1) / gridDim.x;
@@ -646,19 +663,28 @@ __global__ __launch_bounds__(256) void k_group_sum(const double *const *__restri
     for (int p = 0; p < parts; p++) recv[p][i] = s;
 }
 
-// Sum of v[0..count) by one 1024-thread block: thread t adds t, t+1024, ... in order, then a tree.
+// Sum of v[0..count) by one 1024-thread block, fixed order: thread t adds t, t+1024, ...; a shuffle tree per wave; the
+// 16 wave sums through LDS and one more shuffle tree.  Two barriers (the ten-round LDS tree it replaces cost k_control
+// and k_final about a microsecond each).
+__device__ __forceinline__ double block_sum(double s, double *sm);
 __device__ __forceinline__ double block_vec_sum(const double *__restrict__ v, int64_t count, double *sm)
 {
-    const int t = threadIdx.x;
     double s = 0.0;
-    for (int64_t q = t; q < count; q += 1024) s += v[q];
-    sm[t] = s;
+    for (int64_t q = threadIdx.x; q < count; q += 1024) s += v[q];
+    return block_sum(s, sm);
+}
+// the block's total of one value per thread (1024 threads), same order as above
+__device__ __forceinline__ double block_sum(double s, double *sm)
+{
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    s = wave_sum(s);
+    if (lane == 0) sm[wave] = s;
     __syncthreads();
-    for (int h = 512; h >= 1; h >>= 1) {
-        if (t < h) sm[t] += sm[t + h];
-        __syncthreads();
-    }
-    return sm[0];
+    double r = lane < 16 ? sm[lane] : 0.0;
+    r = wave_sum(r);                                  // every wave forms the same total in its lane 0 ...
+    r = __shfl(r, 0, 64);                             // ... and hands it to all its lanes
+    __syncthreads();                                  // sm may be reused by the caller
+    return r;
 }
 
 // tail = [rowSum(eh)_k (R) | sum H-terms | sum log lh | data term | sum lgamma(x+1)] of THIS partition.
@@ -695,13 +721,15 @@ __global__ __launch_bounds__(1024) void k_final(const double *__restrict__ bpW, 
 {
     __shared__ double sW[R + 2], sT[R + 4];
     __shared__ double sm[1024];
-    bp_colsums(bpW, nbW, R + 2, sW, 1024);
     if (tail_in) {
+        bp_colsums(bpW, nbW, R + 2, sW, 1024);
         if (threadIdx.x < R + 4) sT[threadIdx.x] = tail_in[threadIdx.x];
         __syncthreads();
     } else {
-        bp_colsums(bpH, nbH, R + 2, sT, 1024);
-        const double data = block_vec_sum(epart, nepart, sm);
+        double part = 0.0;                       // the three reductions' loads travel together
+        for (int64_t q = threadIdx.x; q < nepart; q += 1024) part += epart[q];
+        bp_colsums2(bpW, bpH, nbW, R + 2, sW, sT, 1024);
+        const double data = block_sum(part, sm);
         if (threadIdx.x == 0) { sT[R + 2] = data; sT[R + 3] = lgx; }
         __syncthreads();
     }
@@ -794,18 +822,22 @@ __global__ __launch_bounds__(1024) void k_control(const double *__restrict__ bpW
                                                   double *__restrict__ out_host, const double *__restrict__ tail_in,
                                                   const double *__restrict__ small_in)
 {
-    if (ctl->stop) return;
     __shared__ double sW[R + 2], sT[R + 4];
     __shared__ double sm[1024];
-    bp_colsums(bpW, nb, R + 2, sW, 1024);
+    const int stopped = ctl->stop;               // tested below, once the loads of the reductions are in flight too
     double data;
     if (tail_in) {
         if (threadIdx.x < R + 2) sT[threadIdx.x] = tail_in[threadIdx.x];
         data = small_in[0]; lgx = small_in[1];
+        bp_colsums(bpW, nb, R + 2, sW, 1024);
+        if (stopped) return;
         __syncthreads();
     } else {
-        bp_colsums(bpH, nb, R + 2, sT, 1024);
-        data = block_vec_sum(epart, nepart, sm);
+        double part = 0.0;                       // this thread's share of the evidence partials
+        for (int64_t q = threadIdx.x; q < nepart; q += 1024) part += epart[q];
+        bp_colsums2(bpW, bpH, nb, R + 2, sW, sT, 1024);
+        if (stopped) return;
+        data = block_sum(part, sm);
     }
     const int lane = threadIdx.x;
     if (lane > 1) return;                        // lanes 0 and 1 go on (the two Newton recurrences of hyper_update)

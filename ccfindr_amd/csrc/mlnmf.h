@@ -28,9 +28,10 @@ __global__ __launch_bounds__(kUpdateThreads) void k_ml_update(
     constexpr int RB = kUpdateThreads / R;       // majors per pass
     __shared__ double s_other[R + 2];
     __shared__ double s_e[kUpdateThreads];
-    if (stop && *stop) return;                   // device-driven loop: the run has ended, leave the factors as they are
+    const int stopped = stop ? *stop : 0;        // device-driven loop: the run has ended, leave the factors as they are
     const int t = threadIdx.x;
-    bp_colsums(other_bp, other_nb, R + 2, s_other, kUpdateThreads);
+    bp_colsums(other_bp, other_nb, R + 2, s_other, kUpdateThreads);       // (its loads travel with the flag's)
+    if (stopped) return;
     __syncthreads();
 
     const int row = t / R, k = t - row * R;
@@ -76,9 +77,10 @@ __global__ __launch_bounds__(1024) void k_ml_final(const double *__restrict__ bp
 {
     __shared__ double sW[R + 2], sH[R + 2];
     __shared__ double sm[1024];
-    bp_colsums(bpW, nb, R + 2, sW, 1024);
-    bp_colsums(bpH, nb, R + 2, sH, 1024);
-    const double data = block_vec_sum(epart, nepart, sm);
+    double part = 0.0;                           // the three reductions' loads travel together
+    for (int64_t q = threadIdx.x; q < nepart; q += 1024) part += epart[q];
+    bp_colsums2(bpW, bpH, nb, R + 2, sW, sH, 1024);
+    const double data = block_sum(part, sm);
     if (threadIdx.x == 0) {
         double cross = 0.0;
         for (int k = 0; k < r; k++) cross += sW[k] * sH[k];
@@ -99,12 +101,14 @@ __global__ __launch_bounds__(1024) void k_ml_control(const double *__restrict__ 
                                                      double n, double m, LoopCtl *ctl, double *__restrict__ history,
                                                      double *__restrict__ out_host)
 {
-    if (ctl->stop) return;
     __shared__ double sW[R + 2], sH[R + 2];
     __shared__ double sm[1024];
-    bp_colsums(bpW, nb, R + 2, sW, 1024);
-    bp_colsums(bpH, nb, R + 2, sH, 1024);
-    const double data = block_vec_sum(epart, nepart, sm);
+    const int stopped = ctl->stop;               // tested once the reductions' loads are in flight too
+    double part = 0.0;
+    for (int64_t q = threadIdx.x; q < nepart; q += 1024) part += epart[q];
+    bp_colsums2(bpW, bpH, nb, R + 2, sW, sH, 1024);
+    if (stopped) return;
+    const double data = block_sum(part, sm);
     if (threadIdx.x != 0) return;
     double cross = 0.0;
     for (int k = 0; k < r; k++) cross += sW[k] * sH[k];
