@@ -35,3 +35,31 @@ a = eng.get_state(("ew",))["ew"]
 assert np.isfinite(a).all() and np.isfinite(out["lkh"])
 eng.close()
 print("soak ok")
+
+# round 2: the partitioned device-driven loop (local group of 4 partitions) and the device-side initialisers, repeatedly
+X = synth.drop_empty(synth.simulate_data(1500, (700,) * 4, seed=2, sparse=True))
+n, m = X.shape
+M = C.CountMatrix(X)
+from ccfindr_amd.parallel import cell_partition
+for rep in range(20):
+    cuts = cell_partition(m, 4)
+    comm = C.Communicator.local(4)
+    parts = [C.VBEngine(M, 8, cols=c, m_global=m) for c in cuts]
+    for p in parts:
+        p.attach_comm(comm)
+        p.random_state(HY, seed=rep)
+    comm.state_finish()
+    res = comm.run(HY, Itmax=300, Tol=1e-6, flags=(True,) * 4)
+    assert np.isfinite(res["lkh"]) and res["it"] >= 11
+    for p in parts:
+        p.close()
+    comm.close()
+    eng = C.VBEngine(M, 14)
+    u, d, vt, it = eng.svd(4)
+    assert np.isfinite(d).all()
+    eng.close()
+torch.cuda.synchronize()
+free2 = torch.cuda.mem_get_info()[0]
+print(f"20 x (4-partition group loop + device SVD): device memory free {free2 / 2**20:.0f} MiB", flush=True)
+assert abs(free2 - free1) < 1024 * 2**20
+print("soak 2 ok")
