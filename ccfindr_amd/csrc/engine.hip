@@ -917,6 +917,8 @@ int group_tables(vbnmf_comm *c)
         const size_t off = (size_t)e->n * e->R + e->R + 2;
         sb[p] = e->red; rb[p] = e->red_g; ss[p] = e->red + off; rs[p] = e->red_g + off;
     }
+    (void)hipFree(c->d_send_big); (void)hipFree(c->d_send_small); (void)hipFree(c->d_recv_big); (void)hipFree(c->d_recv_small);
+    c->d_send_big = c->d_send_small = nullptr; c->d_recv_big = c->d_recv_small = nullptr;      // (tables of an earlier membership)
     if (int rc = dev_alloc(&c->d_send_big, (size_t)P)) return rc;
     if (int rc = dev_alloc(&c->d_send_small, (size_t)P)) return rc;
     if (int rc = dev_alloc(&c->d_recv_big, (size_t)P)) return rc;
@@ -1193,6 +1195,11 @@ int vbnmf_engine_attach_comm(vbnmf_engine *e, vbnmf_comm *c)
 {
     if (!e || !c) return fail(VBNMF_ERR_BAD_ARG, "NULL argument");
     if (e->comm) return fail(VBNMF_ERR_STATE, "the engine already has a communicator");
+    {   // engines that were destroyed while attached leave empty seats: a communicator none of whose engines is alive starts over
+        bool any = false;
+        for (vbnmf_engine *q : c->members) any |= q != nullptr;
+        if (!any) c->members.clear();
+    }
     if (e->device != c->device) return fail(VBNMF_ERR_BAD_ARG, "engine on device %d, communicator on device %d", e->device, c->device);
     if (c->kind == 0 && !c->members.empty()) return fail(VBNMF_ERR_STATE, "an RCCL communicator serves one engine per process");
     if (c->kind == 1 && (int)c->members.size() >= c->nranks) return fail(VBNMF_ERR_STATE, "the local group is full");
