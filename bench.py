@@ -16,13 +16,16 @@ repeat bracketed by a barrier + device synchronise; all five times are reported)
   * stepped from the host (vbnmf_engine_step: one call and one read-back of lkh + statistics per iteration, SURVEY.md
     section 8(d)'s literal metric) -> `host_stepped`.
 The roofline figures of k_sweep come from HIP events around its launches, on the engine's stream, in the host-stepped
-pass.  `roofline.traffic` is NOT measured in this run: it is the HBM byte count of the rocprofv3 --pmc passes kept
+pass (mean per repeat, median over the five repeats, all five in `kernel_ms_repeats`).  `roofline.traffic` is NOT measured in this run: it is the HBM byte count of the rocprofv3 --pmc passes kept
 under profiles/ (`traffic_source` names the file).
 
 CPU references timed in the same run, on rank 0 at N = 1: `cpu_baseline` = the oracle's stored-entries step with
 OpenMP on the box's cores (kind "port"); `cpu_reference_literal` = the oracle's LITERAL restatement of
 src/vbnmf_update.cpp (dense, same operation order, ONE thread -- the reference builds without OpenMP, src/Makevars:1-2)
 at a stated down-scale of the same matrix, with ns per matrix element and the extrapolation to the full size.
+
+After the W warm-up steps the engine runs untimed settle steps (to ~0.3 s of load in all, `config.settle_steps`) so that
+a short K measures the chip at its loaded clocks, not on its way up from idle.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--mode restarts|cells] [--small]
 
@@ -166,8 +169,8 @@ def cells_partitioned_sample(world, rank, local_rank, barrier, steps):
     return out, times
 
 
-def timed_repeats(fn, barrier, repeats=5):
-    """`repeats` x [barrier, fn(), barrier] -> list of seconds."""
+def timed_repeats(fn, barrier, repeats=5, after=None):
+    """`repeats` x [barrier, fn(), barrier] -> list of seconds; `after()` runs outside the timed region of every repeat."""
     out = []
     for _ in range(repeats):
         barrier()
@@ -175,6 +178,8 @@ def timed_repeats(fn, barrier, repeats=5):
         fn()
         barrier()
         out.append(time.perf_counter() - t0)
+        if after is not None:
+            after()
     return out
 
 
@@ -250,6 +255,16 @@ def main():
         lkh, _ = step()
         gpu_lk.append(lkh)
 
+    # Clock settle: the driver may ask for a very short run (K = 20, W = 5 is ~7 ms of GPU work), and the chip needs tens
+    # of milliseconds of load to leave its idle clocks (k_sweep reads 215 us in the first 5 ms after start-up and 179 us
+    # 25 ms later).  After the W warm-up steps, untimed steps are added until ~0.3 s of stepping lie behind the engine.
+    settle = max(0, 1200 - args.warmup)
+    if hasattr(eng, "run") and getattr(eng, "native", True):
+        eng.run(HYPER, Itmax=settle, Tol=0.0, n0=10, dn=1, flags=(False,) * 4)
+    else:
+        for _ in range(settle):
+            step()
+
     base_eng = getattr(eng, "engine", eng)
     REPEATS = 5
     last = {}
@@ -259,10 +274,13 @@ def main():
             last["lkh"], _ = step()
 
     base_eng.timing_enable(True)
-    host_times = timed_repeats(host_pass, barrier, REPEATS)
+    sweep_repeats = []                           # mean k_sweep time (HIP events on the engine's stream) of every repeat
+    host_times = timed_repeats(host_pass, barrier, REPEATS, after=lambda: sweep_repeats.append(base_eng.timing_get()))
     dt = float(np.median(host_times))
     lkh = last["lkh"]
-    sweep_ms, sweep_cnt = base_eng.timing_get()
+    per_repeat_ms = [ms / cnt for ms, cnt in sweep_repeats if cnt]
+    sweep_cnt = sum(cnt for _, cnt in sweep_repeats)
+    sweep_ms = (float(np.median(per_repeat_ms)) * sweep_cnt) if per_repeat_ms else 0.0      # median repeat, as for `value`
 
     # The same K steps with the loop driven by the device (vbnmf_engine_run: the product's default path,
     # ccfindr_amd/bayesian.py::vb_run_rank): hyper_update and the stopping rule of vb_iterate evaluated on the GPU,
@@ -384,11 +402,13 @@ def main():
             "config": {"workload": name, "n_genes": n, "n_cells": m, "nnz": nnz, "rank": r,
                        "mode": args.mode if world > 1 else "single", "hyper": "fixed aw=bw=ah=bh=1",
                        "loop": loop, "lkh_last": lkh_dev if dt_dev is not None else lkh,
-                       "timing": f"median of {REPEATS} repeats of the {args.steps}-step region"},
+                       "timing": f"median of {REPEATS} repeats of the {args.steps}-step region",
+                       "settle_steps": settle},
             "roofline": {"bound": "hbm", "kernel": "k_sweep", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": bytes_sweep, "kernel_ms": sweep_s * 1e3,
+                         "kernel_ms_repeats": per_repeat_ms,
                          "streamed_bytes_per_launch": info["stream_bytes_per_step"]},
             # SURVEY.md section 8(d) asks for both fractions: algorithmic flops = 10 r per stored entry
             "roofline_fp64": {"bound": "fp64-valu", "kernel": "k_sweep", "flops_per_launch": 10 * r * nnz,
