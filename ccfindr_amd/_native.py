@@ -22,7 +22,7 @@ c_int64_p = ctypes.POINTER(ctypes.c_int64)
 c_uint32_p = ctypes.POINTER(ctypes.c_uint32)
 
 OK, ERR_BAD_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_STATE = range(6)
-MAX_RANK = 32
+MAX_RANK = 64
 COMM_ID_BYTES = 128
 
 

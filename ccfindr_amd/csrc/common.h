@@ -108,7 +108,10 @@ struct LayoutParams {
 };
 
 // Padded rank used on the device (even, so a factor row is a whole number of 16-byte LDS reads).
-inline int padded_rank(int r) { return (r + 1) & ~1; }
+// Ranks up to 32 are padded to even; above, SP = 2 (to 64) or 4 (to 128) lanes of the sweep share a task's R * SP
+// columns (kernels.h: sweep_side), R a multiple of 4 between 20 and 32: multiples of 8, then of 16.
+inline int padded_rank(int r) { return r <= 32 ? (r + 1) & ~1 : (r <= 64 ? (r + 7) & ~7 : (r + 15) & ~15); }
+constexpr int rank_shares(int RT) { return RT <= 32 ? 1 : (RT <= 64 ? 2 : 4); }
 // Bytes of one factor row in the sweep's LDS image: R doubles, padded to an odd number of 16-byte
 // bank slots so that rows congruent mod 16 (and only those) start in the same slot.
 constexpr int lds_row_bytes(int R) { return ((R / 2) | 1) * 16; }
@@ -136,7 +139,9 @@ constexpr int kLdsReserveBytes = 4112;
 #ifndef VBNMF_ONEBUF_UPTO
 #define VBNMF_ONEBUF_UPTO 0         // experiments: padded ranks <= this ALSO use the one-buffer loop
 #endif
-constexpr int sweep_threads(int R) { return R <= VBNMF_T1024_UPTO ? 1024 : (R <= VBNMF_T768_UPTO ? 768 : (R <= VBNMF_T512_UPTO ? 512 : 256)); }
+constexpr int sweep_threads_lane(int R) { return R <= VBNMF_T1024_UPTO ? 1024 : (R <= VBNMF_T768_UPTO ? 768 : (R <= VBNMF_T512_UPTO ? 512 : 256)); }
+// by the padded rank RT: the geometry of the per-lane rank RT / shares
+constexpr int sweep_threads(int RT) { return sweep_threads_lane(RT / rank_shares(RT)); }
 // Default block width / task length for a side at padded rank R with `nnz` stored entries (0: unknown, longest
 // tasks); n_wg <= 0 picks the default (256).
 LayoutParams default_layout_params(int64_t n_major, int64_t n_minor, int R, int n_wg = 0, int64_t nnz = 0);

@@ -228,30 +228,32 @@ int prepare_sweep_kernel(const void *fn)
 }
 
 // ---- dispatch over the padded rank (compile-time so factor rows live in registers) ----
-template <int R, bool WIDE, int NT>
+template <int R, bool WIDE, int NT, int SP>
 int launch_sweep_t(vbnmf_engine *e, const SweepSide &a, const SweepSide &b)
 {
     static std::atomic<bool> attr_set[16];
-    const void *fn = (const void *)k_sweep<R, WIDE, NT>;
+    const void *fn = (const void *)k_sweep<R, WIDE, NT, SP>;
     if (e->device >= 16 || !attr_set[e->device].load(std::memory_order_acquire)) {
         if (int rc = prepare_sweep_kernel(fn)) return rc;
         if (e->device < 16) attr_set[e->device].store(true, std::memory_order_release);
     }
     const unsigned grid = (unsigned)e->n_wg;
-    hipLaunchKernelGGL((k_sweep<R, WIDE, NT>), dim3(grid), dim3(NT), e->lds_bytes, e->stream, a, b);
+    hipLaunchKernelGGL((k_sweep<R, WIDE, NT, SP>), dim3(grid), dim3(NT), e->lds_bytes, e->stream, a, b);
     HIPCHECK(hipGetLastError());
     return VBNMF_OK;
 }
 
-template <int R>
+// RT: the padded rank; above 32 the sweep's lanes share it (SP lanes of R = RT / SP columns each, kernels.h)
+template <int RT>
 int launch_sweep_r(vbnmf_engine *e, const SweepSide &a, const SweepSide &b)
 {
-    constexpr int NT = sweep_threads(R);
-    return e->wide ? launch_sweep_t<R, true, NT>(e, a, b) : launch_sweep_t<R, false, NT>(e, a, b);
+    constexpr int SP = rank_shares(RT), R = RT / SP, NT = sweep_threads(RT);
+    return e->wide ? launch_sweep_t<R, true, NT, SP>(e, a, b) : launch_sweep_t<R, false, NT, SP>(e, a, b);
 }
 
 #define VBNMF_FOR_EACH_R(X) \
-    X(2) X(4) X(6) X(8) X(10) X(12) X(14) X(16) X(18) X(20) X(22) X(24) X(26) X(28) X(30) X(32)
+    X(2) X(4) X(6) X(8) X(10) X(12) X(14) X(16) X(18) X(20) X(22) X(24) X(26) X(28) X(30) X(32) \
+    X(40) X(48) X(56) X(64)
 
 int launch_sweep(vbnmf_engine *e)
 {
@@ -343,35 +345,35 @@ int launch_pack(vbnmf_engine *e)
 }
 
 // ---- ML-NMF (mlnmf.h): single-side sweeps and the multiplicative updates ----
-template <int R, bool WIDE, bool LOGTERM, int NT, bool VB = false>
+template <int R, bool WIDE, bool LOGTERM, int NT, int SP, bool VB = false>
 int launch_sweep1_t(vbnmf_engine *e, const SweepSide &a)
 {
     static std::atomic<bool> attr_set[16];
-    const void *fn = (const void *)k_sweep1<R, WIDE, LOGTERM, NT, VB>;
+    const void *fn = (const void *)k_sweep1<R, WIDE, LOGTERM, NT, VB, SP>;
     if (e->device >= 16 || !attr_set[e->device].load(std::memory_order_acquire)) {
         if (int rc = prepare_sweep_kernel(fn)) return rc;
         if (e->device < 16) attr_set[e->device].store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL((k_sweep1<R, WIDE, LOGTERM, NT, VB>), dim3((unsigned)e->n_wg), dim3(NT), e->lds_bytes, e->stream, a);
+    hipLaunchKernelGGL((k_sweep1<R, WIDE, LOGTERM, NT, VB, SP>), dim3((unsigned)e->n_wg), dim3(NT), e->lds_bytes, e->stream, a);
     HIPCHECK(hipGetLastError());
     return VBNMF_OK;
 }
 
 // One side of the VB sweep alone (cell-partitioned device loop): gene side with the log term, cell side without.
-template <int R>
+template <int RT>
 int launch_vb_side_r(vbnmf_engine *e, const SweepSide &a, bool gene_side)
 {
-    constexpr int NT = sweep_threads(R);
-    if (e->wide) return gene_side ? launch_sweep1_t<R, true, true, NT, true>(e, a) : launch_sweep1_t<R, true, false, NT, true>(e, a);
-    return gene_side ? launch_sweep1_t<R, false, true, NT, true>(e, a) : launch_sweep1_t<R, false, false, NT, true>(e, a);
+    constexpr int SP = rank_shares(RT), R = RT / SP, NT = sweep_threads(RT);
+    if (e->wide) return gene_side ? launch_sweep1_t<R, true, true, NT, SP, true>(e, a) : launch_sweep1_t<R, true, false, NT, SP, true>(e, a);
+    return gene_side ? launch_sweep1_t<R, false, true, NT, SP, true>(e, a) : launch_sweep1_t<R, false, false, NT, SP, true>(e, a);
 }
 
-template <int R>
+template <int RT>
 int launch_sweep1_r(vbnmf_engine *e, const SweepSide &a, bool logterm)
 {
-    constexpr int NT = sweep_threads(R);
-    if (e->wide) return logterm ? launch_sweep1_t<R, true, true, NT>(e, a) : launch_sweep1_t<R, true, false, NT>(e, a);
-    return logterm ? launch_sweep1_t<R, false, true, NT>(e, a) : launch_sweep1_t<R, false, false, NT>(e, a);
+    constexpr int SP = rank_shares(RT), R = RT / SP, NT = sweep_threads(RT);
+    if (e->wide) return logterm ? launch_sweep1_t<R, true, true, NT, SP>(e, a) : launch_sweep1_t<R, true, false, NT, SP>(e, a);
+    return logterm ? launch_sweep1_t<R, false, true, NT, SP>(e, a) : launch_sweep1_t<R, false, false, NT, SP>(e, a);
 }
 
 // gene side: lanes own genes (F = w, G = h), statistics for the W update; cell side: F = h, G = w, statistics
@@ -439,25 +441,25 @@ int launch_ml_final(vbnmf_engine *e)
 }
 
 // ---- sparse products on the tiled layout (k_spmm) ----
-template <int R, bool WIDE, int NT>
+template <int R, bool WIDE, int NT, int SP>
 int launch_spmm_t(vbnmf_engine *e, const SweepSide &a)
 {
     static std::atomic<bool> attr_set[16];
-    const void *fn = (const void *)k_spmm<R, WIDE, NT>;
+    const void *fn = (const void *)k_spmm<R, WIDE, NT, SP>;
     if (e->device >= 16 || !attr_set[e->device].load(std::memory_order_acquire)) {
         if (int rc = prepare_sweep_kernel(fn)) return rc;
         if (e->device < 16) attr_set[e->device].store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL((k_spmm<R, WIDE, NT>), dim3((unsigned)e->n_wg), dim3(NT), e->lds_bytes, e->stream, a);
+    hipLaunchKernelGGL((k_spmm<R, WIDE, NT, SP>), dim3((unsigned)e->n_wg), dim3(NT), e->lds_bytes, e->stream, a);
     HIPCHECK(hipGetLastError());
     return VBNMF_OK;
 }
 
-template <int R>
+template <int RT>
 int launch_spmm_r(vbnmf_engine *e, const SweepSide &a)
 {
-    constexpr int NT = sweep_threads(R);
-    return e->wide ? launch_spmm_t<R, true, NT>(e, a) : launch_spmm_t<R, false, NT>(e, a);
+    constexpr int SP = rank_shares(RT), R = RT / SP, NT = sweep_threads(RT);
+    return e->wide ? launch_spmm_t<R, true, NT, SP>(e, a) : launch_spmm_t<R, false, NT, SP>(e, a);
 }
 
 // Wait for k_final's sequence flag in pinned memory; falls back to the stream if it takes long.

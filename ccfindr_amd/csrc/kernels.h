@@ -110,13 +110,14 @@ __device__ __forceinline__ void lds_row(const double2 *__restrict__ ldsG, uint32
     for (int kk = 0; kk < R / 2; kk++) { const Pair v = g[kk]; gv[kk] = make_double2(v.x, v.y); }
 }
 
+// share: byte offset of the lane's share of the row (ranks above 32, see sweep_side; 0 otherwise and folded away)
 template <int R>
-__device__ __forceinline__ Group4 unpack4(const uint4 e)
+__device__ __forceinline__ Group4 unpack4(const uint4 e, uint32_t share = 0)
 {
     // the word carries the row's byte offset inside the staged block (one AND) and the count (one shift), common.h
     Group4 g;
-    g.o0 = e.x & 0x3FFF0u; g.o1 = e.y & 0x3FFF0u;
-    g.o2 = e.z & 0x3FFF0u; g.o3 = e.w & 0x3FFF0u;
+    g.o0 = (e.x & 0x3FFF0u) + share; g.o1 = (e.y & 0x3FFF0u) + share;
+    g.o2 = (e.z & 0x3FFF0u) + share; g.o3 = (e.w & 0x3FFF0u) + share;
     g.c0 = e.x >> 18; g.c1 = e.y >> 18; g.c2 = e.z >> 18; g.c3 = e.w >> 18;
     return g;
 }
@@ -130,7 +131,24 @@ __device__ __forceinline__ Group4 unpack4(const uint4 e)
 // ONE: the entry is a stored one (x is not read): q = 1 / wth, and on the side that carries the evidence's
 // sum x log(wth) the logarithm is deferred -- the lane multiplies wth into a running product (renormalised every two
 // entries, so any wth in 2^+-500 is safe) and takes ONE logarithm per slice: ~2.5 instructions per entry instead of ~18.
-template <int R, bool SPMM = false, bool ONE = false>
+// Ranks above 32: SP = 2 or 4 neighbouring lanes share one task, each holding R of its R * SP columns (sweep_side);
+// the dot product's shares are added across the SP lanes with DPP quad permutes (no LDS traffic).  a + b is
+// commutative in IEEE arithmetic, so every lane of the group holds the same wth.
+template <int SP>
+__device__ __forceinline__ double share_sum(double v)
+{
+    if (SP >= 2) {
+        const int lo = __double2loint(v), hi = __double2hiint(v);
+        v += __hiloint2double(__builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, false), __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, false));
+    }
+    if (SP >= 4) {
+        const int lo = __double2loint(v), hi = __double2hiint(v);
+        v += __hiloint2double(__builtin_amdgcn_mov_dpp(hi, 0x4E, 0xF, 0xF, false), __builtin_amdgcn_mov_dpp(lo, 0x4E, 0xF, 0xF, false));
+    }
+    return v;
+}
+
+template <int R, bool SPMM = false, bool ONE = false, int SP = 1>
 __device__ __forceinline__ void sweep_entry(SweepRegs<R> &S, const double2 *__restrict__ ldsG, const double2 (&gv)[R / 2],
                                             double x, bool logterm)
 {
@@ -141,7 +159,7 @@ __device__ __forceinline__ void sweep_entry(SweepRegs<R> &S, const double2 *__re
             w0 = fma(S.F[2 * kk], gv[kk].x, w0);
             w1 = fma(S.F[2 * kk + 1], gv[kk].y, w1);
         }
-        const double wth = w0 + w1;
+        const double wth = share_sum<SP>(w0 + w1);
         const double rc = sp_rcp_seed(wth);
         const double q = fma(fma(-wth, rc, 1.0), rc, rc);          // 1 / wth to 2^-48, as dev_div_fast
 #pragma unroll
@@ -167,7 +185,7 @@ __device__ __forceinline__ void sweep_entry(SweepRegs<R> &S, const double2 *__re
         w0 = fma(S.F[2 * kk], gv[kk].x, w0);
         w1 = fma(S.F[2 * kk + 1], gv[kk].y, w1);
     }
-    const double wth = w0 + w1;
+    const double wth = share_sum<SP>(w0 + w1);
     const double q = dev_div_fast(x, wth);
 #pragma unroll
     for (int kk = 0; kk < R / 2; kk++) {
@@ -207,10 +225,17 @@ __device__ __forceinline__ int take_ticket(int *ticket)
 // EV selects the per-slice scalar left in the evidence slots: 1 = the VB data term sum(acc . llF) - sum x log(wth)
 // (see the header), 2 = sum x log(wth) alone (ML-NMF likelihood, mlnmf.h), 0 = nothing, 3 = nothing and the entries
 // are accumulated as a plain sparse product (k_spmm).
-template <int R, bool WIDE, bool LOGTERM, int NT, int EV = 1>
+// SP (1, 2 or 4): ranks above 32.  The factor rows have RT = R * SP columns; SP neighbouring lanes share a task, lane
+// share hp holding columns [hp R, (hp + 1) R) of the major's row, of the accumulators and of every gathered row.  A
+// slice still has 64 tasks: the wave runs it as SP sub-slices of 64 / SP tasks, one after the other.
+template <int R, bool WIDE, bool LOGTERM, int NT, int EV = 1, int SP = 1>
 __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restrict__ ldsG)
 {
+    constexpr int RT = R * SP;
+    constexpr int TL = 64 / SP;                            // tasks per sub-slice
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tl = lane / SP, hp = lane % SP;              // task lane inside the sub-slice, share of the row
+    const uint32_t share = (uint32_t)hp * (R * 8);
     // workgroups that share an XCD (blockIdx % 8) take neighbouring ranges, i.e. mostly the same blocks
     const int nwg = S.n_wg;
     const int wg = (nwg % 8 == 0) ? (int)(blockIdx.x % 8) * (nwg / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
@@ -227,12 +252,12 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
         __syncthreads();                                   // readers of the previous block are done
         if (threadIdx.x == 0) *ticket = 0;
         {
-            constexpr int kSlots = (R / 2) | 1;            // LDS row stride in 16-byte slots (odd)
-            const double2 *G2 = reinterpret_cast<const double2 *>(S.G + (size_t)m0 * R);
-            const int cnt = cw * (R / 2);
+            constexpr int kSlots = (RT / 2) | 1;           // LDS row stride in 16-byte slots (odd)
+            const double2 *G2 = reinterpret_cast<const double2 *>(S.G + (size_t)m0 * RT);
+            const int cnt = cw * (RT / 2);
             double2 *rows = ldsG + kLdsRowBase / sizeof(double2);
             for (int t = threadIdx.x; t < cnt; t += NT) {
-                const int row = t / (R / 2), kk = t - row * (R / 2);
+                const int row = t / (RT / 2), kk = t - row * (RT / 2);
                 rows[row * kSlots + kk] = G2[t];
             }
             if (threadIdx.x < kLogTabSize) ldsG[threadIdx.x] = reinterpret_cast<const double2 *>(S.logtab)[threadIdx.x];
@@ -248,12 +273,16 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
             const int i = take_ticket(ticket);
             if (i >= cn) break;
             const int s = c0 + i;                          // slices are numbered in processing order
-            const uint32_t M = S.task_major[(size_t)s * 64 + lane];
             const int ng = S.slice_width[s] >> 2;
             const int64_t off = S.slice_off[s];
+            double ev = 0.0;                               // the lane's evidence contribution over the sub-slices
+#pragma unroll 1
+            for (int sub = 0; sub < SP; sub++) {
+            const int tlane = sub * TL + tl;               // the task's lane in the slice's lane-interleaved storage
+            const uint32_t M = S.task_major[(size_t)s * 64 + tlane];
             SweepRegs<R> T;
             if (M != kIdle) {
-                const double2 *F2 = reinterpret_cast<const double2 *>(S.F + (size_t)M * R);
+                const double2 *F2 = reinterpret_cast<const double2 *>(S.F + (size_t)M * RT + hp * R);
 #pragma unroll
                 for (int kk = 0; kk < R / 2; kk++) { double2 v = F2[kk]; T.F[2 * kk] = v.x; T.F[2 * kk + 1] = v.y; }
             } else {
@@ -273,38 +302,38 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
             if ((R >= VBNMF_ONEBUF_FROM || R <= VBNMF_ONEBUF_UPTO) && !WIDE) {
                 // very large ranks: the factor row, the accumulators and ONE gathered row already fill
                 // the register file, so no second row buffer and no look-ahead here
-                const uint4 *E = reinterpret_cast<const uint4 *>(S.packed + off) + lane;
+                const uint4 *E = reinterpret_cast<const uint4 *>(S.packed + off) + tlane;
                 const int ngf = (EV == 3) ? 0 : min(ng, S.slice_fast[s] >> 2);      // groups inside the leading stretch of ones
                 int g = 0;
                 for (; g < ngf; g++) {
-                    const Group4 a = unpack4<R>(E[(size_t)g * 64]);
-                    lds_row<R>(ldsG, a.o0, g0); sweep_entry<R, false, true>(T, ldsG, g0, 1.0, LOGTERM);
-                    lds_row<R>(ldsG, a.o1, g0); sweep_entry<R, false, true>(T, ldsG, g0, 1.0, LOGTERM);
+                    const Group4 a = unpack4<R>(E[(size_t)g * 64], share);
+                    lds_row<R>(ldsG, a.o0, g0); sweep_entry<R, false, true, SP>(T, ldsG, g0, 1.0, LOGTERM);
+                    lds_row<R>(ldsG, a.o1, g0); sweep_entry<R, false, true, SP>(T, ldsG, g0, 1.0, LOGTERM);
                     if (LOGTERM) renorm_product<R>(T);
-                    lds_row<R>(ldsG, a.o2, g0); sweep_entry<R, false, true>(T, ldsG, g0, 1.0, LOGTERM);
-                    lds_row<R>(ldsG, a.o3, g0); sweep_entry<R, false, true>(T, ldsG, g0, 1.0, LOGTERM);
+                    lds_row<R>(ldsG, a.o2, g0); sweep_entry<R, false, true, SP>(T, ldsG, g0, 1.0, LOGTERM);
+                    lds_row<R>(ldsG, a.o3, g0); sweep_entry<R, false, true, SP>(T, ldsG, g0, 1.0, LOGTERM);
                     if (LOGTERM) renorm_product<R>(T);
                 }
                 for (; g < ng; g++) {
-                    const Group4 a = unpack4<R>(E[(size_t)g * 64]);
-                    lds_row<R>(ldsG, a.o0, g0); sweep_entry<R, EV == 3>(T, ldsG, g0, (double)a.c0, LOGTERM);
-                    lds_row<R>(ldsG, a.o1, g0); sweep_entry<R, EV == 3>(T, ldsG, g0, (double)a.c1, LOGTERM);
-                    lds_row<R>(ldsG, a.o2, g0); sweep_entry<R, EV == 3>(T, ldsG, g0, (double)a.c2, LOGTERM);
-                    lds_row<R>(ldsG, a.o3, g0); sweep_entry<R, EV == 3>(T, ldsG, g0, (double)a.c3, LOGTERM);
+                    const Group4 a = unpack4<R>(E[(size_t)g * 64], share);
+                    lds_row<R>(ldsG, a.o0, g0); sweep_entry<R, EV == 3, false, SP>(T, ldsG, g0, (double)a.c0, LOGTERM);
+                    lds_row<R>(ldsG, a.o1, g0); sweep_entry<R, EV == 3, false, SP>(T, ldsG, g0, (double)a.c1, LOGTERM);
+                    lds_row<R>(ldsG, a.o2, g0); sweep_entry<R, EV == 3, false, SP>(T, ldsG, g0, (double)a.c2, LOGTERM);
+                    lds_row<R>(ldsG, a.o3, g0); sweep_entry<R, EV == 3, false, SP>(T, ldsG, g0, (double)a.c3, LOGTERM);
                 }
                 if (LOGTERM && ngf > 0)
                     T.lsum += fma((double)T.pexp, 6.93147180559945286227e-01, dev_log_tab(T.prod, reinterpret_cast<const LogTabEntry *>(ldsG)));
             } else if (!WIDE) {
                 double2 g1[R / 2];
-                const uint4 *E = reinterpret_cast<const uint4 *>(S.packed + off) + lane;
-                Group4 a = unpack4<R>(E[0]), b = unpack4<R>(E[64]);
+                const uint4 *E = reinterpret_cast<const uint4 *>(S.packed + off) + tlane;
+                Group4 a = unpack4<R>(E[0], share), b = unpack4<R>(E[64], share);
                 lds_row<R>(ldsG, a.o0, g0);
                 // FENCE keeps the machine scheduler from sinking a row's LDS reads down to their first
                 // use: the reads of entry j+1 stay in front of the arithmetic of entry j, which hides them.
 #define VBNMF_FENCE() __builtin_amdgcn_sched_barrier(0)
                 // One trip = 8 entries (two 4-entry groups).  ONE = the trip lies in the slice's leading stretch of
                 // stored ones (layout: slice_fast), PIN = the matching pin of the next trip's unpacked groups.
-#define VBNMF_ENTRY(ONE, gv, cnt) sweep_entry<R, EV == 3, ONE>(T, ldsG, gv, (double)(cnt), LOGTERM); VBNMF_FENCE()
+#define VBNMF_ENTRY(ONE, gv, cnt) sweep_entry<R, EV == 3, ONE, SP>(T, ldsG, gv, (double)(cnt), LOGTERM); VBNMF_FENCE()
 #define VBNMF_TRIP(ONE, PIN)                                                                      \
                 {                                                                                 \
                     const int pn = min(p + 1, np - 1);                    /* last trip re-reads itself */ \
@@ -326,12 +355,12 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
                     if (ONE && LOGTERM) renorm_product<R>(T);                                     \
                     lds_row<R>(ldsG, b.o3, g1); VBNMF_FENCE();                                    \
                     VBNMF_ENTRY(ONE, g0, b.c2);                                                   \
-                    a = unpack4<R>(ec);                                                           \
+                    a = unpack4<R>(ec, share);                                                    \
                     PIN(a);                                                                       \
                     lds_row<R>(ldsG, a.o0, g0); VBNMF_FENCE();                                    \
                     VBNMF_ENTRY(ONE, g1, b.c3);                                                   \
                     if (ONE && LOGTERM) renorm_product<R>(T);                                     \
-                    b = unpack4<R>(ed);                                                           \
+                    b = unpack4<R>(ed, share);                                                    \
                     PIN(b);                                                                       \
                 }
                 const int npf = (EV == 3) ? 0 : min(np, S.slice_fast[s] >> 3);
@@ -346,40 +375,42 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
 #undef VBNMF_FENCE
             } else {
                 double2 g1[R / 2];
-                const uint4 *E = reinterpret_cast<const uint4 *>(S.widx + off) + lane;
-                const double2 *V = reinterpret_cast<const double2 *>(S.wval + off) + lane * 2;
+                const uint4 *E = reinterpret_cast<const uint4 *>(S.widx + off) + tlane;
+                const double2 *V = reinterpret_cast<const double2 *>(S.wval + off) + tlane * 2;
                 for (int g = 0; g < ng; g++) {
                     const uint4 c = E[(size_t)g * 64];
                     const double2 v0 = V[(size_t)g * 128], v1 = V[(size_t)g * 128 + 1];
-                    lds_row<R>(ldsG, c.x * (((R / 2) | 1) * 16), g0);
-                    lds_row<R>(ldsG, c.y * (((R / 2) | 1) * 16), g1);
-                    sweep_entry<R, EV == 3>(T, ldsG, g0, v0.x, LOGTERM);
-                    lds_row<R>(ldsG, c.z * (((R / 2) | 1) * 16), g0);
-                    sweep_entry<R, EV == 3>(T, ldsG, g1, v0.y, LOGTERM);
-                    lds_row<R>(ldsG, c.w * (((R / 2) | 1) * 16), g1);
-                    sweep_entry<R, EV == 3>(T, ldsG, g0, v1.x, LOGTERM);
-                    sweep_entry<R, EV == 3>(T, ldsG, g1, v1.y, LOGTERM);
+                    lds_row<R>(ldsG, c.x * (((RT / 2) | 1) * 16) + share, g0);
+                    lds_row<R>(ldsG, c.y * (((RT / 2) | 1) * 16) + share, g1);
+                    sweep_entry<R, EV == 3, false, SP>(T, ldsG, g0, v0.x, LOGTERM);
+                    lds_row<R>(ldsG, c.z * (((RT / 2) | 1) * 16) + share, g0);
+                    sweep_entry<R, EV == 3, false, SP>(T, ldsG, g1, v0.y, LOGTERM);
+                    lds_row<R>(ldsG, c.w * (((RT / 2) | 1) * 16) + share, g1);
+                    sweep_entry<R, EV == 3, false, SP>(T, ldsG, g0, v1.x, LOGTERM);
+                    sweep_entry<R, EV == 3, false, SP>(T, ldsG, g1, v1.y, LOGTERM);
                 }
             }
 
             // partial statistics of this task and the lane's evidence contribution
-            double ev = 0.0;
             {
-                double2 *P = reinterpret_cast<double2 *>(S.part + ((size_t)s * 64 + lane) * R);
+                double2 *P = reinterpret_cast<double2 *>(S.part + ((size_t)s * 64 + tlane) * RT + hp * R);
 #pragma unroll
                 for (int kk = 0; kk < R / 2; kk++) P[kk] = make_double2(T.acc[2 * kk], T.acc[2 * kk + 1]);
             }
             if (EV == 1 && M != kIdle) {
-                const double2 *L2 = reinterpret_cast<const double2 *>(S.llF + (size_t)M * R);
+                const double2 *L2 = reinterpret_cast<const double2 *>(S.llF + (size_t)M * RT + hp * R);
+                double evt = 0.0;
 #pragma unroll
                 for (int kk = 0; kk < R / 2; kk++) {
                     const double2 l = L2[kk];
-                    ev = fma(T.acc[2 * kk], l.x, ev);
-                    ev = fma(T.acc[2 * kk + 1], l.y, ev);
+                    evt = fma(T.acc[2 * kk], l.x, evt);
+                    evt = fma(T.acc[2 * kk + 1], l.y, evt);
                 }
-                ev -= T.lsum;
+                if (hp == 0) evt -= T.lsum;               // every lane of the group holds the task's sum x log(wth)
+                ev += evt;
             }
-            if (EV == 2 && M != kIdle) ev = T.lsum;
+            if (EV == 2 && M != kIdle && hp == 0) ev += T.lsum;
+            }                                              // sub-slices
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) ev += __shfl_down(ev, d, 64);
             if (lane == 0) ev_slot[i] = ev;                // this slice's evidence partial
@@ -404,35 +435,35 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
     }
 }
 
-template <int R, bool WIDE, int NT>
+template <int R, bool WIDE, int NT, int SP = 1>
 __global__ __launch_bounds__(NT) void k_sweep(const SweepSide A, const SweepSide B)
 {
     extern __shared__ double2 ldsG[];
     if (A.stop && *A.stop) return;               // the driver loop has ended: leave the statistics as they are
-    sweep_side<R, WIDE, true, NT>(A, ldsG);      // lanes own genes: statistics sw + the sum x log(wth)
-    sweep_side<R, WIDE, false, NT>(B, ldsG);     // lanes own cells: statistics sh
+    sweep_side<R, WIDE, true, NT, 1, SP>(A, ldsG);      // lanes own genes: statistics sw + the sum x log(wth)
+    sweep_side<R, WIDE, false, NT, 1, SP>(B, ldsG);     // lanes own cells: statistics sh
 }
 
 // One side alone (ML-NMF: its H and W updates are sequential, reference R/factorize.R:8-24, so each needs its
 // own pass over X; the cell-side pass also yields the likelihood's sum x log(wh)).
 // VB = true: one side of the VB sweep launched alone, with the VB evidence partial (EV = 1): cell-partitioned engines
 // run the gene side first, so that its statistics can be all-reduced while the cell side runs.
-template <int R, bool WIDE, bool LOGTERM, int NT, bool VB = false>
+template <int R, bool WIDE, bool LOGTERM, int NT, bool VB = false, int SP = 1>
 __global__ __launch_bounds__(NT) void k_sweep1(const SweepSide S)
 {
     extern __shared__ double2 ldsG[];
     if (S.stop && *S.stop) return;               // device-driven loop: the run has ended
-    sweep_side<R, WIDE, LOGTERM, NT, VB ? 1 : (LOGTERM ? 2 : 0)>(S, ldsG);
+    sweep_side<R, WIDE, LOGTERM, NT, VB ? 1 : (LOGTERM ? 2 : 0), SP>(S, ldsG);
 }
 
 // Sparse product on the tiled layout (the truncated SVD behind the svd2 initialiser,
 // reference R/bayesian.R:150-159 irlba): per task sum_minor x * G[minor, :] -- X G on the gene side, t(X) G on the
 // cell side -- into the same per-task partials, which k_pack then sums per major.
-template <int R, bool WIDE, int NT>
+template <int R, bool WIDE, int NT, int SP = 1>
 __global__ __launch_bounds__(NT) void k_spmm(const SweepSide S)
 {
     extern __shared__ double2 ldsG[];
-    sweep_side<R, WIDE, false, NT, 3>(S, ldsG);
+    sweep_side<R, WIDE, false, NT, 3, SP>(S, ldsG);
 }
 
 // Sum of one major's task partials for column k, in the inverse index's fixed order.  The

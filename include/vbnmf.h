@@ -45,7 +45,10 @@ typedef enum {
     VBNMF_ERR_STATE = 5        /* call sequence error (e.g. step before set_state)              */
 } vbnmf_status;
 
-#define VBNMF_MAX_RANK 32
+/* Largest rank an engine takes.  The reference's only bound is rank <= min(n, m) (R/bayesian.R:319-320); here the
+ * factor rows live in registers: up to 32 columns per lane, and above that two lanes share a task (ranks 33..64, padded
+ * to a multiple of 8). */
+#define VBNMF_MAX_RANK 64
 
 /* Message of the calling thread's most recent failure ("" if none). Never NULL. */
 const char *vbnmf_last_error(void);
