@@ -161,7 +161,8 @@ def vb_init(nrow, ncol, mat, rank, hyper, initializer, max=1.0, rng=None, device
     with a numpy Generator (R's RNG stream cannot be reproduced outside R); ``svd2`` takes
     |U| and |D V^T| of a rank-``rank`` SVD rescaled so mean(h) = bh -- the full SVD on the host for small
     matrices, as the reference does (:151-152), otherwise the truncated one on the device
-    (``ccfindr_amd.linalg.truncated_svd`` in place of irlba, :154); ``svd`` is the NNDSVD-like start (:116-149)."""
+    (``ccfindr_amd.linalg.truncated_svd`` in place of irlba, :154); ``svd`` is the NNDSVD-like start (:116-149), from
+    the same leading triplets."""
     if initializer == "random":
         if rng is None:
             rng = np.random.default_rng()
@@ -186,8 +187,17 @@ def vb_init(nrow, ncol, mat, rank, hyper, initializer, max=1.0, rng=None, device
         # positive branch (:135-138) is always taken; and :125, whose seq(2, rank) makes rank = 1 an error in R.
         if rank < 2:
             raise ValueError("initializer 'svd' needs rank >= 2 (reference R/bayesian.R:125 indexes component 2)")
-        A = mat.toarray() if hasattr(mat, "toarray") else np.asarray(mat, dtype=np.float64)
-        u, d, vt = np.linalg.svd(A, full_matrices=False)                                        # :119
+        # :119 asks for nu = nv = rank and reads d[1..rank] only: the leading triplets are all it needs, so a large
+        # (or already ingested) matrix goes through the device's truncated SVD instead of a dense full one, under
+        # svd2's rule (:151-154); a dense array is decomposed on the host as the reference does.  The triplets' signs are
+        # LAPACK's in the reference and the device's here: either is an arbitrary choice the formulas below depend on.
+        stored_sparse = isinstance(mat, CountMatrix) or hasattr(mat, "toarray")
+        if not stored_sparse or (min(nrow, ncol) / 2 <= rank and not isinstance(mat, CountMatrix)):
+            A = mat.toarray() if hasattr(mat, "toarray") else np.asarray(mat, dtype=np.float64)
+            u, d, vt = np.linalg.svd(A, full_matrices=False)                                    # :119
+        else:
+            from .linalg import truncated_svd
+            u, d, vt = truncated_svd(mat, rank, seed=0 if rng is None else int(rng.integers(1 << 31)), device=device)
         w = np.zeros((nrow, rank)); h = np.zeros((rank, ncol))                                  # :117-118
         d1 = np.sqrt(d[0])                                                                      # :120
         w[:, 0] = d1 * u[:, 0]                                                                  # :121

@@ -3,7 +3,7 @@ between: dense stateless entry and the resident engine (whose evidence comes fro
 import numpy as np
 import pytest
 
-from util_mp_step import CASES, make_case, step
+from util_mp_step import CASES, make_case, ml_step, step
 
 pytestmark = pytest.mark.gpu
 
@@ -29,3 +29,18 @@ def test_engine_against_50_digit_step(case, noninteger):
     lkh, _ = eng.step(hyper, fudge)
     assert abs(lkh / float(want["lkh"]) - 1) <= 1e-12
     eng.close()
+
+
+@pytest.mark.parametrize("prior", [False, True])
+@pytest.mark.parametrize("n,m,r,seed", [(7, 9, 3, 1), (12, 6, 2, 2), (5, 14, 4, 3)])
+def test_ml_engine_against_50_digit_step(n, m, r, seed, prior):
+    import ccfindr_amd as C
+    rng = np.random.default_rng(seed)
+    X, _ = make_case(n, m, r, 1.1, {"aw": 1.0, "bw": 1.0, "ah": 1.0, "bh": 1.0}, 0.0, seed, noninteger=bool(seed % 2))
+    w, h = rng.uniform(0.05, 1.0, size=(n, r)), rng.uniform(0.05, 1.0, size=(r, m))
+    ew, eh, lk = ml_step(X, w, h, prior, 1.7, 0.6)
+    got = C.nmf_update(X, w, h, prior=prior, gamma_a=1.7, gamma_b=0.6)
+    assert relerr(got["ew"], ew) <= 1e-13 and relerr(got["eh"], eh) <= 1e-13
+    wh = ew @ eh
+    scale = (np.abs(X * np.log(wh)).sum() + wh.sum()) / n / m
+    assert abs(got["lk"] - float(lk)) <= 1e-12 * scale

@@ -62,6 +62,34 @@ def planted(n, m, k, seed):
     return X
 
 
+def test_svd_initialiser_on_device_matches_host_svd_up_to_the_triplets_signs():
+    """vb_init(initializer = 'svd') (reference R/bayesian.R:116-149) reads the leading `rank` triplets only: beyond
+    min(nrow, ncol)/2 > rank they come from the device's truncated SVD.  The formulas depend on each triplet's sign
+    (LAPACK's in the reference, arbitrary): the host's triplets are aligned to the device's before comparing."""
+    from ccfindr_amd import bayesian, linalg
+    import ccfindr_amd as C
+    from oracle import vbnmf_oracle as O
+    X = planted(300, 500, 4, seed=11)
+    hy = {"aw": 1.0, "bw": 1.0, "ah": 1.0, "bh": 1.0}
+    rank = 4
+    got = bayesian.vb_init(300, 500, sp.csc_matrix(X), rank, hy, "svd", rng=np.random.default_rng(3))
+    assert (got["w"] >= 0).all() and (got["h"] >= 0).all() and not got["dw"].any()
+    U, D, Vt = np.linalg.svd(X, full_matrices=False)
+    # the leading pair is sign-free: the Perron pair
+    assert np.allclose(np.outer(got["w"][:, 0], got["h"][0]), D[0] * np.outer(U[:, 0], Vt[0]), rtol=1e-6, atol=1e-8)
+    for k in range(1, rank):
+        cands = []
+        for sgn in (1.0, -1.0):                                    # the two sign choices of triplet k
+            x, y = sgn * U[:, k], sgn * Vt[k]
+            xp, yp = np.where(x > 0, x, 0.0), np.where(y > 0, y, 0.0)
+            sig = np.linalg.norm(xp) * np.linalg.norm(yp)          # :132-138 (the positive branch is always taken)
+            cands.append((np.sqrt(D[k] * sig) * xp / np.linalg.norm(xp), np.sqrt(D[k] * sig) * yp / np.linalg.norm(yp)))
+        err = [max(np.max(np.abs(got["w"][:, k] - w)), np.max(np.abs(got["h"][k] - h))) for w, h in cands]
+        assert min(err) <= 1e-6 * max(np.max(cands[0][0]), np.max(cands[0][1])), (k, err)
+    res = C.vb_factorize(sp.csc_matrix(X), ranks=rank, nrun=1, initializer="svd", verbose=0, Itmax=30)
+    assert res.basis[0].shape == (300, rank) and np.isfinite(res.measure["lml"][0])
+
+
 @pytest.mark.parametrize("n,m,k", [(400, 900, 4), (1200, 700, 6)])
 def test_truncated_svd_matches_full_svd(n, m, k):
     from ccfindr_amd.linalg import truncated_svd

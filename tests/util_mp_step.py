@@ -101,3 +101,48 @@ def make_case(n, m, r, lam, hyper, fudge, seed, noninteger=False):
           "lh": rng.gamma(hyper["ah"], hyper["bh"] / hyper["ah"], size=(r, m)) + 1e-3}
     wh["ew"], wh["eh"] = wh["lw"].copy(), rng.gamma(2.0, 0.5, size=(r, m))
     return np.asfortranarray(X), wh
+
+
+def ml_step(X, w, h, prior=False, gamma_a=1.0, gamma_b=1.0, eps=2.220446049250313e-16):
+    """nmf_updateR + likelihood in 50 digits, reference R/factorize.R:2-27 and :40-49.  Returns (ew, eh, lk)."""
+    Xm, W, H = _mat(X), _mat(w), _mat(h)
+    n, m, r = Xm.rows, Xm.cols, W.cols
+    ga, gb, e = mp.mpf(float(gamma_a)), mp.mpf(float(gamma_b)), mp.mpf(float(eps))
+
+    def ratio(W, H):
+        wh = W * H
+        q = mp.matrix(n, m)
+        for i in range(n):
+            for j in range(m):
+                q[i, j] = Xm[i, j] / wh[i, j]
+        return q
+
+    t = W.T * ratio(W, H)                                                 # :8
+    cs = [mp.fsum(W[i, k] for i in range(n)) for k in range(r)]           # :9
+    Hn = mp.matrix(r, m)
+    for k in range(r):
+        for j in range(m):
+            up, down = H[k, j] * t[k, j], cs[k]
+            if prior:
+                up, down = up + ga - 1, down + ga / gb                    # :11-12
+            v = up / down                                                 # :14
+            Hn[k, j] = e if v < e else v                                  # :15
+    t = ratio(W, Hn) * Hn.T                                               # :17 (the NEW h)
+    rs = [mp.fsum(Hn[k, j] for j in range(m)) for k in range(r)]          # :18
+    Wn = mp.matrix(n, r)
+    for i in range(n):
+        for k in range(r):
+            up, down = W[i, k] * t[i, k], rs[k]
+            if prior:
+                up, down = up + ga - 1, down + ga / gb                    # :20-21
+            v = up / down                                                 # :23
+            Wn[i, k] = e if v < e else v                                  # :24
+    wh = Wn * Hn                                                          # :42
+    lk = mp.mpf(0)
+    for i in range(n):
+        for j in range(m):
+            x = Xm[i, j]
+            lk += x * mp.log(wh[i, j]) - wh[i, j]                         # :44
+            if x > 0:
+                lk += -x * mp.log(x) + x                                  # :45-46
+    return _np(Wn), _np(Hn), lk / n / m                                   # :47
