@@ -8,6 +8,8 @@ wrappers raise ``VBNMFError``.
 from __future__ import annotations
 
 import ctypes
+import sys
+import importlib.util
 import os
 
 import numpy as np
@@ -130,6 +132,15 @@ def load():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `make` (or `python -c 'import __graft_entry__ as g; g.build()'`). "
             "ccfindr_amd has no CPU fallback.")
+    # One HIP runtime per process.  PyTorch ships its own libamdhip64; a process that maps this library (and with it
+    # /opt/rocm's runtime) first and torch's afterwards ends with two runtimes, and the second one finds no device
+    # ("No HIP GPUs are available" from torch.cuda).  With torch mapped first both use torch's copy.  So: torch first,
+    # when it is installed (it is plumbing here -- device tensors, torch.distributed -- and optional).
+    if "torch" not in sys.modules and importlib.util.find_spec("torch") is not None:
+        try:
+            import torch  # noqa: F401
+        except Exception:  # noqa: BLE001 -- a broken torch must not keep the engine from loading
+            pass
     L = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(L, name)          # AttributeError here = header/library mismatch
