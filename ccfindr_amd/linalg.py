@@ -1,7 +1,7 @@
 """Truncated SVD of the count matrix on the MI355X engine: the ``irlba::irlba(mat, rank)`` of the reference's
 ``svd2`` initialiser (R/bayesian.R:150-159) with its two sparse products ``X V`` and ``t(X) U`` run by the sweep
 machinery (``k_spmm``) and, by default, everything else on the device as well (``vbnmf_engine_svd``: the subspace
-never leaves HBM inside the iteration); k = rank + oversampling <= 32.
+never leaves HBM inside the iteration); k = rank + oversampling <= 64 (VBNMF_MAX_RANK).
 
 irlba is an implicitly restarted Lanczos bidiagonalisation with ``tol = 1e-5``; this is block subspace iteration with
 the same kind of stopping rule (relative change of the leading singular values) and a tighter default, so the
