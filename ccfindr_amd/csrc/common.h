@@ -69,7 +69,7 @@ double sum_xlogx(const Matrix &X, int64_t cb, int64_t ce);
 // them through a ticket counter, so a segment is just the id range [seg_ptr[g], seg_ptr[g+1]).
 constexpr int kLanes = 64;          // one slice = one wavefront
 constexpr int kUnroll = 4;          // entries per lane per 16-byte load
-constexpr int kWidthQuantum = 8;    // slice widths are multiples of this (two loads per loop trip)
+constexpr int kWidthQuantum = 4;    // slice widths are multiples of this (one 4-entry group of the packed stream)
 constexpr uint32_t kIdleLane = 0xFFFFFFFFu;
 // Packed entry word: bits 4..17 = the LDS slot (16-byte unit) of the minor's factor row, already shifted into a
 // byte offset (word & kPackedOffsetMask); bits 18..31 = the count.  Padding slots are 0 (row 0, count 0).

@@ -550,7 +550,7 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
             L.slice_block[s] = blk;
             int32_t f = INT32_MAX;                               // leading entries that are ones in EVERY lane (idle lanes: none)
             for (int l = 0; l < kLanes; l++) f = std::min(f, task_n1[(size_t)s * kLanes + l]);
-            L.slice_fast[s] = f / kWidthQuantum * kWidthQuantum;  // whole loop trips
+            L.slice_fast[s] = f / 8 * 8;                           // whole loop trips (8 entries)
         }
     }
     btasks.clear();

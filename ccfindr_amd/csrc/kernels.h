@@ -295,8 +295,9 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
             T.prod = 1.0;
             T.pexp = 0;
 
-            // Slice widths are multiples of 8: two 4-entry groups per trip, the loads of the
-            // next trip issued before this trip's arithmetic, LDS rows fetched one entry ahead.
+            // Slice widths are multiples of 4 (one group of the packed stream): two 4-entry groups per trip, the loads
+            // of the next trip issued before this trip's arithmetic, LDS rows fetched one entry ahead; an odd last
+            // group runs as half a trip behind the loop.
             const int np = ng >> 1;
             double2 g0[R / 2];
             if ((R >= VBNMF_ONEBUF_FROM || R <= VBNMF_ONEBUF_UPTO) && !WIDE) {
@@ -326,7 +327,7 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
             } else if (!WIDE) {
                 double2 g1[R / 2];
                 const uint4 *E = reinterpret_cast<const uint4 *>(S.packed + off) + tlane;
-                Group4 a = unpack4<R>(E[0], share), b = unpack4<R>(E[64], share);
+                Group4 a = unpack4<R>(E[0], share), b = unpack4<R>(E[(size_t)min(1, ng - 1) * 64], share);
                 lds_row<R>(ldsG, a.o0, g0);
                 // FENCE keeps the machine scheduler from sinking a row's LDS reads down to their first
                 // use: the reads of entry j+1 stay in front of the arithmetic of entry j, which hides them.
@@ -336,8 +337,8 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
 #define VBNMF_ENTRY(ONE, gv, cnt) sweep_entry<R, EV == 3, ONE, SP>(T, ldsG, gv, (double)(cnt), LOGTERM); VBNMF_FENCE()
 #define VBNMF_TRIP(ONE, PIN)                                                                      \
                 {                                                                                 \
-                    const int pn = min(p + 1, np - 1);                    /* last trip re-reads itself */ \
-                    const uint4 ec = E[(size_t)pn * 128], ed = E[(size_t)pn * 128 + 64];          \
+                    /* the next trip's groups; past the end: the last group again (an odd one is the tail's) */ \
+                    const uint4 ec = E[(size_t)min(2 * p + 2, ng - 1) * 64], ed = E[(size_t)min(2 * p + 3, ng - 1) * 64]; \
                     lds_row<R>(ldsG, a.o1, g1); VBNMF_FENCE();                                    \
                     VBNMF_ENTRY(ONE, g0, a.c0);                                                   \
                     lds_row<R>(ldsG, a.o2, g0); VBNMF_FENCE();                                    \
@@ -368,6 +369,15 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
                 for (; p < npf - 1; p++) VBNMF_TRIP(true, pin_offsets)
                 if (p < npf) { VBNMF_TRIP(true, pin) p++; }               // the next trip reads the counts again
                 for (; p < np; p++) VBNMF_TRIP(false, pin)
+                if (ng & 1) {                                             // the odd last group: `a` holds it, its first row is in g0
+                    lds_row<R>(ldsG, a.o1, g1); VBNMF_FENCE();
+                    VBNMF_ENTRY(false, g0, a.c0);
+                    lds_row<R>(ldsG, a.o2, g0); VBNMF_FENCE();
+                    VBNMF_ENTRY(false, g1, a.c1);
+                    lds_row<R>(ldsG, a.o3, g1); VBNMF_FENCE();
+                    VBNMF_ENTRY(false, g0, a.c2);
+                    VBNMF_ENTRY(false, g1, a.c3);
+                }
                 if (LOGTERM && npf > 0)                                   // the deferred logarithm of the leading ones
                     T.lsum += fma((double)T.pexp, 6.93147180559945286227e-01, dev_log_tab(T.prod, reinterpret_cast<const LogTabEntry *>(ldsG)));
 #undef VBNMF_TRIP

@@ -362,7 +362,7 @@ typedef struct {
     int64_t n_slots;               /* padded entry slots (all slices) */
     int64_t n_segs;                /* segment = the slices of one block in one workgroup's share */
     const uint32_t *task_major;    /* [n_slices*64] major of task slice*64+lane, 0xFFFFFFFF = idle lane */
-    const int32_t *slice_width;    /* [n_slices] entries per lane (multiple of 8) */
+    const int32_t *slice_width;    /* [n_slices] entries per lane (multiple of 4) */
     const int64_t *slice_off;      /* [n_slices] first slot of the slice; slot(t, lane) =
                                       off + (t/4)*256 + lane*4 + t%4 */
     const int32_t *slice_block;    /* [n_slices] minor block */

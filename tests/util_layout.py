@@ -51,7 +51,7 @@ def reconstruct(view):
     for s in range(view["n_slices"]):
         blk = view["slice_block"][s]
         w, off = view["slice_width"][s], view["slice_off"][s]
-        assert w % 8 == 0 and w >= 8 and w <= view["max_len"] and off % 256 == 0
+        assert w % 4 == 0 and w >= 4 and w <= view["max_len"] and off % 256 == 0
         lens = []
         ones = []                                                  # per lane: its leading stretch of stored ones
         for lane in range(64):
@@ -90,9 +90,9 @@ def reconstruct(view):
                 n1 = int(is1.sum())
                 assert is1[:n1].all()
                 ones.append(n1)
-        padded = [(q + 7) // 8 for q in lens]
+        padded = [(q + 3) // 4 for q in lens]
         assert padded == sorted(padded, reverse=True)          # longest (padded) task first: width = first lane
-        assert (w - lens[0]) < 8
+        assert (w - lens[0]) < 4
         fast = int(view["slice_fast"][s])
         assert fast % 8 == 0 and 0 <= fast <= min(ones) and (view["wide"] == 0 or fast == 0)
     assert ntask == view["n_tasks"]
