@@ -1,0 +1,69 @@
+"""Kernel paths that the default geometry only reaches on matrices too big for a unit test, forced through the
+layout's environment switches: more minor blocks than workgroups (a workgroup walks SEVERAL segments, each with its own
+staged block and ticket list), tasks cut into many short pieces, very few workgroups, workgroup counts that are not a
+multiple of 8 (no XCD remapping).  VB step, resident steps and the ML step against the oracles."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HY = {"aw": 1.2, "bw": 0.9, "ah": 0.8, "bh": 1.5}
+
+
+def relerr(a, b):
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300)))
+
+
+def counts(n, m, seed, noninteger=False):
+    rng = np.random.default_rng(seed)
+    X = rng.poisson(0.5, size=(n, m)).astype(np.float64)
+    X[np.arange(n), rng.integers(0, m, n)] += 1.0
+    X[rng.integers(0, n, m), np.arange(m)] += 1.0
+    X[3, :] += 1.0                                             # a dense gene: many pieces per block
+    if noninteger:
+        X = X * rng.uniform(0.5, 1.5, size=(1, m))
+    return np.asfortranarray(X)
+
+
+@pytest.mark.parametrize("r,lds_kb,nwg,max_len,noninteger", [
+    (3, 8, 5, 16, False),        # ~100-minor blocks, 5 workgroups: several segments per workgroup
+    (10, 8, 3, 8, False),        # shortest tasks (two groups), 3 workgroups
+    (10, 8, 7, 32, True),        # wide layout (value + index streams)
+    (30, 16, 4, 16, False),      # one-row-buffer loop
+    (40, 24, 6, 16, False),      # two lanes per task
+    (64, 32, 9, 24, True),       # two lanes per task, wide layout
+])
+def test_many_segments_per_workgroup(monkeypatch, r, lds_kb, nwg, max_len, noninteger):
+    import ccfindr_amd as C
+    from ccfindr_amd import synth
+    from oracle import vbnmf_oracle as O
+    from oracle import mlnmf_oracle as OM
+    monkeypatch.setenv("VBNMF_LDS_KB", str(lds_kb))
+    monkeypatch.setenv("VBNMF_NWG", str(nwg))
+    monkeypatch.setenv("VBNMF_MAX_LEN", str(max_len))
+    n, m = 260, 700
+    X = counts(n, m, r + nwg, noninteger)
+    M = C.CountMatrix(X)
+    from util_layout import build_layout
+    v = build_layout(M, 0, r)                                  # the same switches cut the host-side copy of the layout
+    assert v["n_wg"] == nwg and v["n_blocks"] > nwg and v["n_segs"] > nwg, (v["n_wg"], v["n_blocks"], v["n_segs"])
+    assert v["wide"] == int(noninteger) and v["max_len"] <= max(max_len, 4)
+    eng = C.VBEngine(M, r)
+    wh = synth.random_state(n, m, r, HY, seed=r)
+    eng.set_state(wh["lw"], wh["lh"], wh["eh"])
+    cur = dict(wh)
+    for step in range(3):
+        lkh, _ = eng.step(HY)
+        cur = O.update_dense(X, cur, HY, C.EPS)
+        assert abs(lkh / cur["lkh"] - 1) <= 1e-10, (step, lkh, cur["lkh"])
+    got = eng.get_state()
+    for k in ("lw", "lh", "ew", "eh", "dw", "dh"):
+        assert relerr(got[k], cur[k]) <= 1e-11, (k, relerr(got[k], cur[k]))
+    rng = np.random.default_rng(1)
+    w, h = rng.uniform(0.05, 1.0, size=(n, r)), rng.uniform(0.05, 1.0, size=(r, m))
+    eng.ml_set_state(w, h)
+    lk = eng.ml_step()
+    ml = eng.ml_get_state()
+    want = OM.nmf_update_literal(X, w, h)
+    assert relerr(ml["ew"], want["ew"]) <= 1e-12 and relerr(ml["eh"], want["eh"]) <= 1e-12
+    eng.close()
