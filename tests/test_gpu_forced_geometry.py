@@ -67,3 +67,41 @@ def test_many_segments_per_workgroup(monkeypatch, r, lds_kb, nwg, max_len, nonin
     want = OM.nmf_update_literal(X, w, h)
     assert relerr(ml["ew"], want["ew"]) <= 1e-12 and relerr(ml["eh"], want["eh"]) <= 1e-12
     eng.close()
+
+
+@pytest.mark.parametrize("r,lds_kb,nwg", [(6, 8, 5), (40, 24, 6)])
+def test_partition_group_loop_with_many_segments(monkeypatch, r, lds_kb, nwg):
+    """The partitioned device loop (split sweep, k_pack, tails, group sum, k_control) on the forced geometry, against
+    the single engine's loop on the default geometry."""
+    import ccfindr_amd as C
+    from ccfindr_amd import synth
+    from ccfindr_amd.parallel import cell_partition
+    n, m = 200, 620
+    X = counts(n, m, 31 + r)
+    M = C.CountMatrix(X)
+    wh = synth.random_state(n, m, r, HY, seed=9)
+    kw = dict(Itmax=14, Tol=0.0, n0=4, dn=1, history=True)
+    whole = C.VBEngine(M, r)                                   # default geometry
+    whole.set_state(wh["lw"], wh["lh"], wh["eh"])
+    want = whole.run(HY, **kw)
+    ref = whole.get_state()
+    monkeypatch.setenv("VBNMF_LDS_KB", str(lds_kb))
+    monkeypatch.setenv("VBNMF_NWG", str(nwg))
+    monkeypatch.setenv("VBNMF_MAX_LEN", "16")
+    cuts = cell_partition(m, 3)
+    comm = C.Communicator.local(len(cuts))
+    parts = [C.VBEngine(M, r, cols=c, m_global=m) for c in cuts]
+    for p, (b, e) in zip(parts, cuts):
+        p.attach_comm(comm)
+        p.set_state(wh["lw"], wh["lh"][:, b:e], wh["eh"][:, b:e])
+    comm.state_finish()
+    got = comm.run(HY, **kw)
+    assert got["it"] == want["it"] == 14
+    assert relerr(got["history"], want["history"]) <= 1e-10
+    st = [p.get_state() for p in parts]
+    assert np.array_equal(st[0]["lw"], st[1]["lw"]) and np.array_equal(st[0]["lw"], st[2]["lw"])
+    assert relerr(st[0]["lw"], ref["lw"]) <= 1e-9
+    assert relerr(np.concatenate([q["lh"] for q in st], axis=1), ref["lh"]) <= 1e-9
+    comm.close()
+    for e in parts + [whole]:
+        e.close()
