@@ -494,7 +494,7 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
     // count conversion, and on the gene side a running product in place of a logarithm per entry, kernels.h).
     // Tasks are therefore grouped by padded length first and, within a length class, by n1: the 64 tasks of a slice
     // then agree on how long that leading stretch is.
-    struct Task { uint32_t major; int32_t len; int64_t pos; int32_t n1; };
+    struct Task { uint32_t major; int32_t len; int64_t pos; int32_t n1, n2; };      // n2: entries of value exactly 2 (placed after the ones)
     const bool fast_ones = !L.wide && env_int("VBNMF_NO_FAST_ONES", 0) == 0;
     std::vector<std::vector<Task>> btasks(nblk);
     parallel_for(nblk, [&](int64_t b0, int64_t b1, int) {
@@ -507,9 +507,9 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
                 int64_t pieces = (cnt + lp.max_len - 1) / lp.max_len;
                 for (int64_t pc = 0; pc < pieces; pc++) {
                     int64_t s = cnt * pc / pieces, t = cnt * (pc + 1) / pieces;
-                    int32_t n1 = 0;
-                    if (fast_ones) for (int64_t q = q0 + s; q < q0 + t; q++) n1 += (val[q] == 1.0);
-                    T.push_back({(uint32_t)M, (int32_t)(t - s), q0 + s, n1});
+                    int32_t n1 = 0, n2 = 0;
+                    if (fast_ones) for (int64_t q = q0 + s; q < q0 + t; q++) { n1 += (val[q] == 1.0); n2 += (val[q] == 2.0); }
+                    T.push_back({(uint32_t)M, (int32_t)(t - s), q0 + s, n1, n2});
                 }
             }
             auto padded = [](int32_t len) { return (len + kWidthQuantum - 1) / kWidthQuantum; };
@@ -537,7 +537,7 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
     L.slice_block.assign(L.n_slices, 0);
     std::vector<int64_t> task_pos((size_t)L.n_slices * kLanes, 0);
     std::vector<int32_t> task_len((size_t)L.n_slices * kLanes, 0);
-    std::vector<int32_t> task_n1((size_t)L.n_slices * kLanes, 0);
+    std::vector<int32_t> task_n1((size_t)L.n_slices * kLanes, 0), task_n2((size_t)L.n_slices * kLanes, 0);
     L.slice_fast.assign(L.n_slices, 0);
     L.n_tasks = 0;
     for (int32_t blk = 0; blk < nblk; blk++) {
@@ -545,15 +545,21 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
         L.n_tasks += (int64_t)T.size();
         for (size_t q = 0; q < T.size(); q++) {
             size_t id = (size_t)bslice0[blk] * kLanes + q;
-            L.task_major[id] = T[q].major; task_pos[id] = T[q].pos; task_len[id] = T[q].len; task_n1[id] = T[q].n1;
+            L.task_major[id] = T[q].major; task_pos[id] = T[q].pos; task_len[id] = T[q].len; task_n1[id] = T[q].n1; task_n2[id] = T[q].n2;
         }
         for (int64_t s = bslice0[blk]; s < bslice0[blk + 1]; s++) {
             int32_t w = task_len[(size_t)s * kLanes];            // sorted by padded length: the first lane's is the largest
             L.slice_width[s] = (w + kWidthQuantum - 1) / kWidthQuantum * kWidthQuantum;
             L.slice_block[s] = blk;
             int32_t f = INT32_MAX;                               // leading entries that are ones in EVERY lane (idle lanes: none)
-            for (int l = 0; l < kLanes; l++) f = std::min(f, task_n1[(size_t)s * kLanes + l]);
-            L.slice_fast[s] = f / 8 * 8;                           // whole loop trips (8 entries)
+            int32_t f12 = INT32_MAX;                             // ... that are ones or twos in every lane (ones first, then twos)
+            for (int l = 0; l < kLanes; l++) {
+                f = std::min(f, task_n1[(size_t)s * kLanes + l]);
+                f12 = std::min(f12, task_n1[(size_t)s * kLanes + l] + task_n2[(size_t)s * kLanes + l]);
+            }
+            const int32_t f1 = f / 8 * 8;                        // whole loop trips (8 entries)
+            const int32_t f2 = std::min<int32_t>(std::max(f1, f12 / 8 * 8), 0xFFF8);
+            L.slice_fast[s] = f1 | (f2 << 16);                   // low half: the stretch of ones; high half: of ones and twos
         }
     }
     btasks.clear();
@@ -604,7 +610,11 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
         // an entry of the leading stretch of ones costs the gene side (which carries the logarithm) ~0.6 and the cell
         // side ~0.9 of an ordinary entry (instruction counts of the two loops, kernels.h)
         const double fast_discount = side == 0 ? 0.4 : 0.1;
-        auto cost = [&](int64_t s) { return (double)L.slice_width[s] - fast_discount * (double)L.slice_fast[s] + c0; };
+        // (the stretch of twos behind the ones saves the gene side's logarithm only: ~0.18 of an entry)
+        auto cost = [&](int64_t s) {
+            const int32_t f1 = L.slice_fast[s] & 0xFFFF, f2 = L.slice_fast[s] >> 16;
+            return (double)L.slice_width[s] - fast_discount * (double)f1 - (side == 0 ? 0.18 : 0.0) * (double)(f2 - f1) + c0;
+        };
         std::vector<double> bcost(nblk, 0.0);
         double total = 0.0;
         for (int32_t blk = 0; blk < nblk; blk++) {
@@ -700,7 +710,7 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
         // Renumber the slices in processing order, so that list position == slice id: the kernel then finds
         // a slice's width, offset, majors and partial rows directly from its ticket, with no indirection.
         const std::vector<int32_t> &ord = order;
-        std::vector<int32_t> w2(L.n_slices), b2(L.n_slices), f2(L.n_slices), len2((size_t)L.n_slices * kLanes), n12((size_t)L.n_slices * kLanes);
+        std::vector<int32_t> w2(L.n_slices), b2(L.n_slices), f2(L.n_slices), len2((size_t)L.n_slices * kLanes), n12((size_t)L.n_slices * kLanes), n22((size_t)L.n_slices * kLanes);
         std::vector<uint32_t> maj2((size_t)L.n_slices * kLanes);
         std::vector<int64_t> pos2((size_t)L.n_slices * kLanes);
         for (int64_t s = 0; s < L.n_slices; s++) {
@@ -711,10 +721,11 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
                 pos2[(size_t)s * kLanes + l] = task_pos[(size_t)o * kLanes + l];
                 len2[(size_t)s * kLanes + l] = task_len[(size_t)o * kLanes + l];
                 n12[(size_t)s * kLanes + l] = task_n1[(size_t)o * kLanes + l];
+                n22[(size_t)s * kLanes + l] = task_n2[(size_t)o * kLanes + l];
             }
         }
         L.slice_width.swap(w2); L.slice_block.swap(b2); L.slice_fast.swap(f2); L.task_major.swap(maj2); task_pos.swap(pos2); task_len.swap(len2);
-        task_n1.swap(n12);
+        task_n1.swap(n12); task_n2.swap(n22);
         int64_t o2 = 0;
         for (int64_t s = 0; s < L.n_slices; s++) { L.slice_off[s] = o2; o2 += (int64_t)L.slice_width[s] * kLanes; }
     }
@@ -746,8 +757,9 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
     const bool schedule = env_int("VBNMF_NO_BANK_SCHEDULE", 0) == 0;
     parallel_for(L.n_slices, [&](int64_t b, int64_t e, int) {
         // [phase][lane in group][residue] -> stack of positions; phase 0 = the task's entries of value 1 (placed
-        // first, see above), phase 1 = the others (every entry when the fast stretch is off)
-        std::vector<int32_t> bucket[2][16][16];
+        // first, see above), phase 1 = those of value 2, phase 2 = the others (every entry when the fast stretch is off)
+        constexpr int NP = 3;
+        std::vector<int32_t> bucket[NP][16][16];
         for (int64_t s = b; s < e; s++) {
             const int32_t m0 = (int32_t)bstart[L.slice_block[s]];
             const int64_t so = L.slice_off[s];
@@ -757,13 +769,13 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
                 if (L.wide) { L.wide_idx[slot] = local; L.wide_val[slot] = val[q]; }
                 else L.packed[slot] = ((uint32_t)val[q] << kPackedCountShift) | ((local * (uint32_t)L.row_slots) << 4);
             };
-            auto phase_of = [&](int64_t q) { return (fast_ones && val[q] == 1.0) ? 0 : 1; };
+            auto phase_of = [&](int64_t q) { return !fast_ones ? 2 : (val[q] == 1.0 ? 0 : (val[q] == 2.0 ? 1 : 2)); };
             if (!schedule) {
                 for (int lane = 0; lane < kLanes; lane++) {
                     size_t id = (size_t)s * kLanes + lane;
                     if (L.task_major[id] == kIdleLane) continue;
                     int64_t t = 0;
-                    for (int ph = 0; ph < 2; ph++)
+                    for (int ph = 0; ph < NP; ph++)
                         for (int64_t u = 0; u < task_len[id]; u++)
                             if (phase_of(task_pos[id] + u) == ph) put(lane, t++, task_pos[id] + u);
                 }
@@ -772,10 +784,11 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
             for (int g = 0; g < 4; g++) {
                 int lanes[16], nl = 0;
                 for (int lane = 0; lane < kLanes; lane++) if (kGroupOf[lane] == g) lanes[nl++] = lane;
-                int cnt[2][16][16] = {}, rem[2][16] = {}, step[16] = {}, dem[16] = {}, nopt[2][16] = {};
+                int cnt[NP][16][16] = {}, rem[NP][16] = {}, step[16] = {}, dem[16] = {}, nopt[NP][16] = {};
+                auto cur = [&](int j) { return rem[0][j] > 0 ? 0 : (rem[1][j] > 0 ? 1 : 2); };        // the phase lane j is in
                 int T = 0;
                 for (int j = 0; j < 16; j++) {
-                    for (int ph = 0; ph < 2; ph++) for (int r = 0; r < 16; r++) bucket[ph][j][r].clear();
+                    for (int ph = 0; ph < NP; ph++) for (int r = 0; r < 16; r++) bucket[ph][j][r].clear();
                     size_t id = (size_t)s * kLanes + lanes[j];
                     if (L.task_major[id] == kIdleLane) continue;
                     const int64_t q0 = task_pos[id];
@@ -786,8 +799,8 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
                         if (cnt[ph][j][r]++ == 0) nopt[ph][j]++;      // nopt: residues the lane still has entries of, per phase
                         rem[ph][j]++;
                     }
-                    for (int r = 0; r < 16; r++) dem[r] += cnt[rem[0][j] > 0 ? 0 : 1][j][r];   // demand of the lanes' CURRENT phases
-                    T = std::max(T, rem[0][j] + rem[1][j]);
+                    for (int r = 0; r < 16; r++) dem[r] += cnt[cur(j)][j][r];   // demand of the lanes' CURRENT phases
+                    T = std::max(T, rem[0][j] + rem[1][j] + rem[2][j]);
                 }
                 for (int t = 0; t < T; t++) {
                     int used[16] = {};
@@ -795,7 +808,6 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
                     int ord[16];
                     for (int r = 0; r < 16; r++) ord[r] = r;
                     std::stable_sort(ord, ord + 16, [&](int x, int y) { return dem[x] > dem[y]; });
-                    auto cur = [&](int j) { return rem[0][j] > 0 ? 0 : 1; };
                     auto take = [&](int j, int r) {
                         size_t id = (size_t)s * kLanes + lanes[j];
                         const int ph = cur(j);
@@ -804,8 +816,10 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
                         put(lanes[j], step[j]++, task_pos[id] + tt);
                         assigned[j] = true; used[r]++; dem[r]--; rem[ph][j]--;
                         if (--cnt[ph][j][r] == 0) nopt[ph][j]--;
-                        if (ph == 0 && rem[0][j] == 0)                        // the lane moves on to its other entries
-                            for (int q = 0; q < 16; q++) dem[q] += cnt[1][j][q];
+                        if (ph < NP - 1 && rem[ph][j] == 0) {                 // the lane moves on to its next kind of entries
+                            const int nx = cur(j);
+                            if (nx != ph && rem[nx][j] > 0) for (int q = 0; q < 16; q++) dem[q] += cnt[nx][j][q];
+                        }
                     };
                     for (int oi = 0; oi < 16; oi++) {
                         const int r = ord[oi];

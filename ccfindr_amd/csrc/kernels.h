@@ -42,7 +42,8 @@ struct SweepSide {
     const double *wval;            // value                                 (wide layout)
     const uint32_t *task_major;    // [n_slices][64]
     const int32_t *slice_width;    // [n_slices]
-    const int32_t *slice_fast;     // [n_slices] leading entries per lane that are stored ones in every lane (multiple of 8)
+    const int32_t *slice_fast;     // [n_slices] low 16 bits: leading entries per lane that are stored ones in every lane
+                                   // (multiple of 8); high 16 bits: ... that are ones or twos in every lane (>= the low half)
     const int64_t *slice_off;      // [n_slices]
     const int32_t *seg_block;      // [n_segs]
     const int32_t *block_start;    // [n_blocks + 1] first minor of each block
@@ -148,7 +149,9 @@ __device__ __forceinline__ double share_sum(double v)
     return v;
 }
 
-template <int R, bool SPMM = false, bool ONE = false, int SP = 1>
+// TWO: the entry is a stored one or two (the stretch behind the leading ones): the ordinary division, but the
+// logarithm is deferred like the ones' -- wth or wth^2 goes into the running product, renormalised after every entry.
+template <int R, bool SPMM = false, bool ONE = false, int SP = 1, bool TWO = false>
 __device__ __forceinline__ void sweep_entry(SweepRegs<R> &S, const double2 *__restrict__ ldsG, const double2 (&gv)[R / 2],
                                             double x, bool logterm)
 {
@@ -191,6 +194,10 @@ __device__ __forceinline__ void sweep_entry(SweepRegs<R> &S, const double2 *__re
     for (int kk = 0; kk < R / 2; kk++) {
         S.acc[2 * kk] = fma(q, gv[kk].x, S.acc[2 * kk]);
         S.acc[2 * kk + 1] = fma(q, gv[kk].y, S.acc[2 * kk + 1]);
+    }
+    if (TWO) {
+        if (logterm) S.prod *= (x == 2.0) ? wth * wth : wth;
+        return;
     }
     if (logterm) S.lsum = fma(x, dev_log_tab(wth, reinterpret_cast<const LogTabEntry *>(ldsG)), S.lsum);
 }
@@ -304,7 +311,7 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
                 // very large ranks: the factor row, the accumulators and ONE gathered row already fill
                 // the register file, so no second row buffer and no look-ahead here
                 const uint4 *E = reinterpret_cast<const uint4 *>(S.packed + off) + tlane;
-                const int ngf = (EV == 3) ? 0 : min(ng, S.slice_fast[s] >> 2);      // groups inside the leading stretch of ones
+                const int ngf = (EV == 3) ? 0 : min(ng, (S.slice_fast[s] & 0xFFFF) >> 2);      // groups inside the leading stretch of ones
                 int g = 0;
                 for (; g < ngf; g++) {
                     const Group4 a = unpack4<R>(E[(size_t)g * 64], share);
@@ -334,51 +341,55 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
 #define VBNMF_FENCE() __builtin_amdgcn_sched_barrier(0)
                 // One trip = 8 entries (two 4-entry groups).  ONE = the trip lies in the slice's leading stretch of
                 // stored ones (layout: slice_fast), PIN = the matching pin of the next trip's unpacked groups.
-#define VBNMF_ENTRY(ONE, gv, cnt) sweep_entry<R, EV == 3, ONE, SP>(T, ldsG, gv, (double)(cnt), LOGTERM); VBNMF_FENCE()
-#define VBNMF_TRIP(ONE, PIN)                                                                      \
+                // MODE: 0 general, 1 the leading ones, 2 the ones-or-twos behind them (gene side only: it defers the logarithm)
+#define VBNMF_ENTRY(MODE, gv, cnt) sweep_entry<R, EV == 3, (MODE) == 1, SP, (MODE) == 2>(T, ldsG, gv, (double)(cnt), LOGTERM); if ((MODE) == 2 && LOGTERM) renorm_product<R>(T); VBNMF_FENCE()
+#define VBNMF_TRIP(MODE, PIN)                                                                     \
                 {                                                                                 \
                     /* the next trip's groups; past the end: the last group again (an odd one is the tail's) */ \
                     const uint4 ec = E[(size_t)min(2 * p + 2, ng - 1) * 64], ed = E[(size_t)min(2 * p + 3, ng - 1) * 64]; \
                     lds_row<R>(ldsG, a.o1, g1); VBNMF_FENCE();                                    \
-                    VBNMF_ENTRY(ONE, g0, a.c0);                                                   \
+                    VBNMF_ENTRY(MODE, g0, a.c0);                                                   \
                     lds_row<R>(ldsG, a.o2, g0); VBNMF_FENCE();                                    \
-                    VBNMF_ENTRY(ONE, g1, a.c1);                                                   \
-                    if (ONE && LOGTERM) renorm_product<R>(T);                                     \
+                    VBNMF_ENTRY(MODE, g1, a.c1);                                                   \
+                    if ((MODE) == 1 && LOGTERM) renorm_product<R>(T);                                     \
                     lds_row<R>(ldsG, a.o3, g1); VBNMF_FENCE();                                    \
-                    VBNMF_ENTRY(ONE, g0, a.c2);                                                   \
+                    VBNMF_ENTRY(MODE, g0, a.c2);                                                   \
                     lds_row<R>(ldsG, b.o0, g0); VBNMF_FENCE();                                    \
-                    VBNMF_ENTRY(ONE, g1, a.c3);                                                   \
-                    if (ONE && LOGTERM) renorm_product<R>(T);                                     \
+                    VBNMF_ENTRY(MODE, g1, a.c3);                                                   \
+                    if ((MODE) == 1 && LOGTERM) renorm_product<R>(T);                                     \
                     lds_row<R>(ldsG, b.o1, g1); VBNMF_FENCE();                                    \
-                    VBNMF_ENTRY(ONE, g0, b.c0);                                                   \
+                    VBNMF_ENTRY(MODE, g0, b.c0);                                                   \
                     lds_row<R>(ldsG, b.o2, g0); VBNMF_FENCE();                                    \
-                    VBNMF_ENTRY(ONE, g1, b.c1);                                                   \
-                    if (ONE && LOGTERM) renorm_product<R>(T);                                     \
+                    VBNMF_ENTRY(MODE, g1, b.c1);                                                   \
+                    if ((MODE) == 1 && LOGTERM) renorm_product<R>(T);                                     \
                     lds_row<R>(ldsG, b.o3, g1); VBNMF_FENCE();                                    \
-                    VBNMF_ENTRY(ONE, g0, b.c2);                                                   \
+                    VBNMF_ENTRY(MODE, g0, b.c2);                                                   \
                     a = unpack4<R>(ec, share);                                                    \
                     PIN(a);                                                                       \
                     lds_row<R>(ldsG, a.o0, g0); VBNMF_FENCE();                                    \
-                    VBNMF_ENTRY(ONE, g1, b.c3);                                                   \
-                    if (ONE && LOGTERM) renorm_product<R>(T);                                     \
+                    VBNMF_ENTRY(MODE, g1, b.c3);                                                   \
+                    if ((MODE) == 1 && LOGTERM) renorm_product<R>(T);                                     \
                     b = unpack4<R>(ed, share);                                                    \
                     PIN(b);                                                                       \
                 }
-                const int npf = (EV == 3) ? 0 : min(np, S.slice_fast[s] >> 3);
+                const int sfast = S.slice_fast[s];
+                const int npf = (EV == 3) ? 0 : min(np, (sfast & 0xFFFF) >> 3);
+                const int npf2 = (EV == 3 || !LOGTERM) ? npf : min(np, sfast >> 19);    // trips of ones or twos (>= npf)
                 int p = 0;
-                for (; p < npf - 1; p++) VBNMF_TRIP(true, pin_offsets)
-                if (p < npf) { VBNMF_TRIP(true, pin) p++; }               // the next trip reads the counts again
-                for (; p < np; p++) VBNMF_TRIP(false, pin)
+                for (; p < npf - 1; p++) VBNMF_TRIP(1, pin_offsets)
+                if (p < npf) { VBNMF_TRIP(1, pin) p++; }                  // the next trip reads the counts again
+                for (; p < npf2; p++) VBNMF_TRIP(2, pin)
+                for (; p < np; p++) VBNMF_TRIP(0, pin)
                 if (ng & 1) {                                             // the odd last group: `a` holds it, its first row is in g0
                     lds_row<R>(ldsG, a.o1, g1); VBNMF_FENCE();
-                    VBNMF_ENTRY(false, g0, a.c0);
+                    VBNMF_ENTRY(0, g0, a.c0);
                     lds_row<R>(ldsG, a.o2, g0); VBNMF_FENCE();
-                    VBNMF_ENTRY(false, g1, a.c1);
+                    VBNMF_ENTRY(0, g1, a.c1);
                     lds_row<R>(ldsG, a.o3, g1); VBNMF_FENCE();
-                    VBNMF_ENTRY(false, g0, a.c2);
-                    VBNMF_ENTRY(false, g1, a.c3);
+                    VBNMF_ENTRY(0, g0, a.c2);
+                    VBNMF_ENTRY(0, g1, a.c3);
                 }
-                if (LOGTERM && npf > 0)                                   // the deferred logarithm of the leading ones
+                if (LOGTERM && npf2 > 0)                                  // the deferred logarithm of the leading ones and twos
                     T.lsum += fma((double)T.pexp, 6.93147180559945286227e-01, dev_log_tab(T.prod, reinterpret_cast<const LogTabEntry *>(ldsG)));
 #undef VBNMF_TRIP
 #undef VBNMF_ENTRY

@@ -366,9 +366,11 @@ typedef struct {
     const int64_t *slice_off;      /* [n_slices] first slot of the slice; slot(t, lane) =
                                       off + (t/4)*256 + lane*4 + t%4 */
     const int32_t *slice_block;    /* [n_slices] minor block */
-    const int32_t *slice_fast;     /* [n_slices] leading entries per lane that are stored ones (value exactly 1) in EVERY
-                                      lane of the slice (multiple of 8; 0 for wide layouts): the sweep runs them through
-                                      a shorter loop.  A task's ones come first, its other entries after them. */
+    const int32_t *slice_fast;     /* [n_slices] low 16 bits: leading entries per lane that are stored ones (value exactly 1) in
+                                      EVERY lane of the slice (multiple of 8; 0 for wide layouts): the sweep runs them through
+                                      a shorter loop; high 16 bits: leading entries that are ones or twos in every lane (>= the
+                                      low half; the gene side defers their logarithm).  A task's ones come first, then its twos,
+                                      then its other entries. */
     const int64_t *block_start;    /* [n_blocks+1] first minor of each block: boundaries sit where the cumulative entry
                                       count reaches a whole number of workgroup quotas */
     const int32_t *seg_block;      /* [n_segs] */

@@ -71,6 +71,12 @@ def _counts(kind, n, m, seed):
     rng = np.random.default_rng(seed)
     if kind == "all_ones":                  # binary matrix: every stored value is 1 -> the whole slice is the leading stretch
         X = (rng.random((n, m)) < 0.25).astype(np.float64)
+    elif kind == "all_twos":                # every stored value is 2: no leading ones, the ones-or-twos stretch is everything
+        X = 2.0 * (rng.random((n, m)) < 0.25).astype(np.float64)
+    elif kind == "ones_and_twos":           # only ones and twos, in varying proportion per gene
+        p2 = rng.uniform(0.05, 0.9, size=(n, 1))
+        X = (rng.random((n, m)) < 0.3).astype(np.float64)
+        X = X * (1.0 + (rng.random((n, m)) < p2))
     elif kind == "no_ones":                 # every stored value >= 2 -> the stretch is empty everywhere
         X = rng.poisson(0.4, size=(n, m)).astype(np.float64)
         X[X > 0] += 1.0
@@ -85,7 +91,7 @@ def _counts(kind, n, m, seed):
     return np.asfortranarray(X)
 
 
-@pytest.mark.parametrize("kind", ["all_ones", "no_ones", "ones_then_big", "mixed"])
+@pytest.mark.parametrize("kind", ["all_ones", "all_twos", "ones_and_twos", "no_ones", "ones_then_big", "mixed"])
 @pytest.mark.parametrize("r", [3, 10, 16, 28, 30])
 def test_leading_ones_stretch_against_the_oracle(kind, r):
     """The sweep's shorter loop over a slice's leading stored ones (layout slice_fast; deferred logarithm through a
@@ -124,3 +130,7 @@ def test_leading_ones_stretch_is_recorded_by_the_layout():
     assert v["slice_fast"].sum() > 0.5 * v["slice_width"].sum()
     v = build_layout(C.CountMatrix(_counts("no_ones", 300, 500, seed=2) + 0.0), 0, 10)
     assert v["slice_fast"].sum() <= 0.05 * v["slice_width"].sum()
+    X2 = 2.0 * (np.random.default_rng(3).random((300, 500)) < 0.3)
+    X2[X2.sum(axis=1) == 0, 0] = 2.0; X2[0, X2.sum(axis=0) == 0] = 2.0
+    v = build_layout(C.CountMatrix(np.asfortranarray(X2)), 0, 10)          # twos only: the second stretch, not the first
+    assert v["slice_fast"].sum() == 0 and v["slice_fast2"].sum() > 0.5 * v["slice_width"].sum()

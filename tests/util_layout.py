@@ -21,7 +21,9 @@ def build_layout(M, side, r, cols=None):
         out["slice_width"] = arr(v.slice_width, v.n_slices)
         out["slice_off"] = arr(v.slice_off, v.n_slices)
         out["slice_block"] = arr(v.slice_block, v.n_slices)
-        out["slice_fast"] = arr(v.slice_fast, v.n_slices)
+        raw = arr(v.slice_fast, v.n_slices)
+        out["slice_fast"] = raw & 0xFFFF                      # the leading stretch of ones ...
+        out["slice_fast2"] = raw >> 16                        # ... and of ones or twos (>= it)
         out["seg_block"] = arr(v.seg_block, v.n_segs)
         out["block_start"] = arr(v.block_start, v.n_blocks + 1)
         out["seg_ptr"] = arr(v.seg_ptr, v.n_segs + 1)
@@ -54,6 +56,7 @@ def reconstruct(view):
         assert w % 4 == 0 and w >= 4 and w <= view["max_len"] and off % 256 == 0
         lens = []
         ones = []                                                  # per lane: its leading stretch of stored ones
+        ones12 = []                                                # per lane: ones and twos
         for lane in range(64):
             tid = s * 64 + lane
             M = view["task_major"][tid]
