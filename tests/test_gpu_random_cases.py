@@ -133,4 +133,4 @@ def test_leading_ones_stretch_is_recorded_by_the_layout():
     X2 = 2.0 * (np.random.default_rng(3).random((300, 500)) < 0.3)
     X2[X2.sum(axis=1) == 0, 0] = 2.0; X2[0, X2.sum(axis=0) == 0] = 2.0
     v = build_layout(C.CountMatrix(np.asfortranarray(X2)), 0, 10)          # twos only: the second stretch, not the first
-    assert v["slice_fast"].sum() == 0 and v["slice_fast2"].sum() > 0.5 * v["slice_width"].sum()
+    assert v["slice_fast"].sum() == 0 and v["slice_fast2"].sum() > 0.4 * v["slice_width"].sum()
