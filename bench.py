@@ -183,6 +183,20 @@ def timed_repeats(fn, barrier, repeats=5, after=None):
     return out
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: run the N ranks under torch.distributed.run as a child process."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:                      # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -196,6 +210,11 @@ def main():
     ap.add_argument("--rank", type=int, default=0, help="diagnostic: another rank on the same matrix (the metric is rank 10)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Bare launch (`python bench.py --gpus N`): this process has not imported torch or touched the GPU, so it starts
+        # the N ranks as CHILD processes (one per GPU, torch.distributed.run on 127.0.0.1), relays their output -- rank 0
+        # prints the JSON line -- and leaves with their status.  Never an exec of a process that holds the GPU.
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -230,7 +249,10 @@ def main():
         name = name.replace("rank 10", f"rank {r} (diagnostic, not the headline rank)")
     n, m = X.shape
     nnz = int(X.nnz)
+    setup = {}                                   # untimed set-up, reported beside the metric (never part of `value`)
+    t_s = time.perf_counter()
     M = C.CountMatrix(X)
+    setup["ingest_s"] = time.perf_counter() - t_s
 
     if args.mode == "cells" and world > 1:
         from ccfindr_amd.parallel import CellPartitionedEngine
@@ -241,9 +263,16 @@ def main():
         units_per_step = 1
         scaling = "strong"
     else:
+        t_s = time.perf_counter()
         eng = C.VBEngine(M, r, device=local_rank)
+        setup["engine_create_s"] = time.perf_counter() - t_s          # tiled layouts of both sides + their upload
         wh0 = synth.random_state(n, m, r, HYPER, seed=1003 + rank)
+        t_s = time.perf_counter()
         eng.set_state(wh0["lw"], wh0["lh"], wh0["eh"])
+        setup["set_state_s"] = time.perf_counter() - t_s              # state upload + the priming sweep
+        t_s = time.perf_counter()
+        C.VBEngine(M, r, device=local_rank).close()
+        setup["engine_create_cached_s"] = time.perf_counter() - t_s   # a second engine on the same matrix and geometry
         step = lambda: eng.step(HYPER)
         units_per_step = world
         scaling = "weak"
@@ -399,6 +428,9 @@ def main():
             "value": value, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "value_host_stepped": host_value, "warmup_effective": args.warmup + settle,
+            "setup": dict(setup, note="seconds, outside every timed region: ingestion of X, engine creation (tiled layouts "
+                                      "cut on the host + upload), initial state + priming sweep"),
             "config": {"workload": name, "n_genes": n, "n_cells": m, "nnz": nnz, "rank": r,
                        "mode": args.mode if world > 1 else "single", "hyper": "fixed aw=bw=ah=bh=1",
                        "loop": loop, "lkh_last": lkh_dev if dt_dev is not None else lkh,
@@ -439,10 +471,13 @@ def main():
         import threading
 
         def give_up():
+            # a collective or the fabric hung: the headline (measured before, without any collective) is still
+            # printed, the hang is recorded in the line, and EVERY rank leaves with a failure status
             if rank == 0:
-                out["cells_partitioned"] = {"error": "timed out (watchdog 420 s)"}
+                out["cells_partitioned"] = {"error": "timed out (watchdog 420 s): the cell-partitioned RCCL sample hung",
+                                            "hang": True}
                 print(json.dumps(out), flush=True)
-            os._exit(0)
+            os._exit(3)
 
         dog = threading.Timer(420.0, give_up)
         dog.daemon = True

@@ -118,6 +118,7 @@ SIGNATURES = {
     "vbnmf_layout_destroy": (None, [_VP]),
     "vbnmf_test_special_host": (ctypes.c_int, [_I32, _I64, c_double_p, c_double_p]),
     "vbnmf_test_special_device": (ctypes.c_int, [_I32, _I64, c_double_p, c_double_p]),
+    "vbnmf_test_stream_sleep": (ctypes.c_int, [_VP, _D]),
 }
 
 _lib = None

@@ -16,11 +16,14 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <new>
+#include <string>
+#include <thread>
 
 #include "common.h"
 #include "comm.h"
@@ -141,6 +144,7 @@ struct vbnmf_engine {
     size_t dbg_count = 0;
     size_t lds_bytes = 0;
     bool has_state = false, stats_ready = false, step_pending = false, prime_pending = false;
+    bool poisoned = false;            // a wait on the device timed out: work may still be queued, nothing is waited for or freed
     bool ml_ready = false;            // lw / lh hold an ML-NMF state (w, h) and the cell-side statistics are current
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
@@ -462,12 +466,32 @@ int launch_spmm_r(vbnmf_engine *e, const SweepSide &a)
     return e->wide ? launch_spmm_t<R, true, NT, SP>(e, a) : launch_spmm_t<R, false, NT, SP>(e, a);
 }
 
+// Wall-clock bound of the host's waits on the device (seconds): VBNMF_WAIT_TIMEOUT_S, default 300.  A wait that
+// exceeds it returns VBNMF_ERR_HIP instead of spinning for ever -- e.g. a cell-partitioned run whose peer died or never
+// enqueued its collective leaves this process's stream on hipErrorNotReady for good (failure modes).
+double wait_timeout_s()
+{
+    if (const char *s = getenv("VBNMF_WAIT_TIMEOUT_S")) {
+        const double v = atof(s);
+        if (v > 0.0) return v;
+    }
+    return 300.0;
+}
+
 // Wait for k_final's sequence flag in pinned memory; falls back to the stream if it takes long.
 int wait_result(vbnmf_engine *e)
 {
     volatile double *flag = e->h_out + 7;
+    const auto t0 = std::chrono::steady_clock::now();
+    const double limit = wait_timeout_s();
     for (long spins = 0; *flag != e->seq; spins++) {
         if (spins > 0 && (spins & 0xFFFF) == 0) {
+            const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (waited > limit) {
+                e->poisoned = true;
+                return fail(VBNMF_ERR_HIP, "timed out after %.1f s (VBNMF_WAIT_TIMEOUT_S) waiting for step %.0f; the last completed step is %.0f",
+                            waited, e->seq, (double)*flag);
+            }
             hipError_t q = hipStreamQuery(e->stream);
             if (q == hipSuccess) {
                 if (*flag == e->seq) break;
@@ -555,6 +579,18 @@ void vbnmf_engine_destroy(vbnmf_engine *e)
 {
     if (!e) return;
     (void)hipSetDevice(e->device);
+    if (e->poisoned) {
+        // A wait timed out earlier.  If the streams have drained since, destroy as usual; if work is still queued (a
+        // collective whose peer is gone), waiting would hang and freeing would pull memory from under queued kernels:
+        // the handle is abandoned -- the process is expected to end with the error it was given.
+        const bool busy = (e->stream && hipStreamQuery(e->stream) == hipErrorNotReady) ||
+                          (e->cstream && hipStreamQuery(e->cstream) == hipErrorNotReady);
+        (void)hipGetLastError();
+        if (busy) {
+            if (e->comm) for (vbnmf_engine *&q : e->comm->members) if (q == e) q = nullptr;
+            return;
+        }
+    }
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->cstream) (void)hipStreamSynchronize(e->cstream);
     if (e->comm) {
@@ -1023,10 +1059,18 @@ int drive_loop(vbnmf_engine *e0, int max_it, QueueStep &&queue_step)
     };
     if (int rc = queue_batch()) return rc;
     if (int rc = queue_batch()) return rc;
+    const double limit = wait_timeout_s();
     for (int b = 0;; b++) {
         const int target = (int)std::min<int64_t>((int64_t)(b + 1) * B, max_it);
+        const auto t0 = std::chrono::steady_clock::now();          // the bound is per batch of B steps
         for (long spins = 1; ho[6] == 0.0 && (int)ho[7] < target; spins++) {
             if ((spins & 0xFFFF) == 0) {
+                const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                if (waited > limit) {
+                    e0->poisoned = true;
+                    return fail(VBNMF_ERR_HIP, "timed out after %.1f s (VBNMF_WAIT_TIMEOUT_S) waiting for step %d of the device-driven loop; "
+                                "the last completed step is %d (%d queued)", waited, target, (int)ho[7], queued);
+                }
                 hipError_t q = hipStreamQuery(e0->stream);
                 if (q != hipSuccess && q != hipErrorNotReady) return fail(VBNMF_ERR_HIP, "the loop failed on the device: %s", hipGetErrorString(q));
                 if (q == hipSuccess && ho[6] == 0.0 && (int)ho[7] < queued) return fail(VBNMF_ERR_HIP, "the device went idle before the queued steps finished");
@@ -1075,6 +1119,11 @@ int run_group(const LoopGroup &G, double *hyper, double fudge, int32_t max_it, d
         e->run_active = true;
     }
     auto cleanup = [&](int rc) {
+        if (e0->poisoned) {                                        // timed out: the streams may never drain -- leave at once
+            std::string msg = last_error_cstr();
+            for (int p = 0; p < G.count; p++) G.e[p]->poisoned = true;
+            return fail(rc, "%s", msg.c_str());
+        }
         for (int p = 0; p < G.count; p++) {
             vbnmf_engine *e = G.e[p];
             (void)hipStreamSynchronize(e->stream);
@@ -1443,6 +1492,7 @@ int vbnmf_engine_ml_run(vbnmf_engine *e, int32_t prior, double gamma_a, double g
     e->timing = false;                                             // event pairs cannot follow launches queued ahead
     e->ev_recorded = false; e->ev2_recorded = false;
     auto done_with = [&](int rc) {
+        if (e->poisoned) return rc;                                 // timed out: the stream may never drain
         (void)hipStreamSynchronize(e->stream);
         e->timing = timing; e->run_active = false;
         e->seq = 0.0; e->h_out[7] = 0.0;                            // the step path's sequence flag restarts
@@ -1809,6 +1859,26 @@ int vbnmf_test_special_device(int32_t kind, int64_t n, const double *x, double *
     return rc;
 }
 
+// Test hook: a host function that sleeps `seconds` is enqueued on the engine's stream, so everything queued behind it
+// waits that long without the GPU being busy or hung (tests/test_gpu_timeouts.py: the bounded waits).
+static void sleep_host_fn(void *arg)
+{
+    const double s = *static_cast<double *>(arg);
+    std::this_thread::sleep_for(std::chrono::duration<double>(s));
+    delete static_cast<double *>(arg);
+}
+
+int vbnmf_test_stream_sleep(vbnmf_engine *e, double seconds)
+{
+    if (!e || !(seconds >= 0.0) || seconds > 60.0) return fail(VBNMF_ERR_BAD_ARG, "engine is NULL or seconds outside [0, 60]");
+    if (int rc = use_device(e)) return rc;
+    double *arg = new (std::nothrow) double(seconds);
+    if (!arg) return fail(VBNMF_ERR_OOM, "out of host memory");
+    hipError_t he = hipLaunchHostFunc(e->stream, sleep_host_fn, arg);
+    if (he != hipSuccess) { delete arg; return fail(VBNMF_ERR_HIP, "hipLaunchHostFunc failed: %s", hipGetErrorString(he)); }
+    return VBNMF_OK;
+}
+
 // ---------------------------------------------------------------- stateless forms
 }  // extern "C"
 
@@ -1824,7 +1894,8 @@ struct StatelessCache {
     bool valid = false;
     int kind = 0;                     // 0 dense, 1 csc
     int64_t n = 0, m = 0, nnz = 0;
-    uint64_t hash = 0;
+    uint64_t hash = 0, hash2 = 0;     // two independently seeded 64-bit hashes of the content: a 128-bit key
+    std::vector<int32_t> colptr;      // csc: a copy of the pointer array, compared on a hit (not only hashed)
     vbnmf_matrix *X = nullptr;
     vbnmf_engine *e = nullptr;
     int r = 0;
@@ -1833,6 +1904,7 @@ struct StatelessCache {
         vbnmf_engine_destroy(e); e = nullptr;
         vbnmf_matrix_destroy(X); X = nullptr;
         valid = false;
+        colptr.clear();
     }
 };
 StatelessCache &stateless_cache() { static StatelessCache c; return c; }
@@ -1871,15 +1943,17 @@ bool stateless_cache_enabled()
 }
 
 // The engine of rank r on the matrix with this key: from the cache, or ingested now through `ingest`.
-int stateless_engine(int kind, int64_t n, int64_t m, int64_t nnz, uint64_t hash, int32_t r,
+int stateless_engine(int kind, int64_t n, int64_t m, int64_t nnz, uint64_t hash, uint64_t hash2, const int32_t *colptr, int32_t r,
                      const std::function<int(vbnmf_matrix **)> &ingest, vbnmf_engine **out)
 {
     StatelessCache &C = stateless_cache();
-    const bool hit = C.valid && C.kind == kind && C.n == n && C.m == m && C.nnz == nnz && C.hash == hash;
+    bool hit = C.valid && C.kind == kind && C.n == n && C.m == m && C.nnz == nnz && C.hash == hash && C.hash2 == hash2;
+    if (hit && colptr) hit = C.colptr.size() == (size_t)m + 1 && std::memcmp(C.colptr.data(), colptr, ((size_t)m + 1) * sizeof(int32_t)) == 0;
     if (!hit) {
         C.drop();
         if (int rc = ingest(&C.X)) { C.X = nullptr; return rc; }
-        C.kind = kind; C.n = n; C.m = m; C.nnz = nnz; C.hash = hash; C.valid = true;
+        C.kind = kind; C.n = n; C.m = m; C.nnz = nnz; C.hash = hash; C.hash2 = hash2; C.valid = true;
+        if (colptr) C.colptr.assign(colptr, colptr + m + 1);
     }
     if (!C.e || C.r != r) {
         vbnmf_engine_destroy(C.e); C.e = nullptr;
@@ -1917,9 +1991,10 @@ int with_dense(int64_t n, int64_t m, int32_t r, const double *X, const std::func
     std::lock_guard<std::mutex> g(C.mu);
     const bool cache = stateless_cache_enabled();
     const uint64_t h = cache ? hash_bytes(X, (size_t)n * (size_t)m * sizeof(double), 0x64656E7365ull) : 0;
+    const uint64_t h2 = cache ? hash_bytes(X, (size_t)n * (size_t)m * sizeof(double), 0x3243F6A8885A308Dull) : 0;
     if (!cache) C.drop();
     vbnmf_engine *e = nullptr;
-    int rc = stateless_engine(0, n, m, 0, h, r, [&](vbnmf_matrix **M) { return vbnmf_matrix_from_dense(n, m, X, M); }, &e);
+    int rc = stateless_engine(0, n, m, 0, h, h2, nullptr, r, [&](vbnmf_matrix **M) { return vbnmf_matrix_from_dense(n, m, X, M); }, &e);
     if (!rc) rc = use(e);
     if (!cache || rc) C.drop();
     return rc;
@@ -1932,16 +2007,22 @@ int with_csc(int64_t n, int64_t m, int32_t r, const int32_t *p, const int32_t *i
     StatelessCache &C = stateless_cache();
     std::lock_guard<std::mutex> g(C.mu);
     const bool cache = stateless_cache_enabled();
+    // the pointer array is checked BEFORE anything is read through it (the hash below walks nnz elements of i and x)
+    if (p[0] != 0) return fail(VBNMF_ERR_BAD_ARG, "pointer array must start at 0");
+    for (int64_t j = 0; j < m; j++)
+        if (p[j + 1] < p[j]) return fail(VBNMF_ERR_BAD_ARG, "pointer array is not non-decreasing at %lld", (long long)j);
     const int64_t nnz = p[m];
-    uint64_t h = 0;
-    if (cache && nnz >= 0 && (nnz == 0 || (i && x))) {
-        h = hash_bytes(p, (size_t)(m + 1) * sizeof(int32_t), 0x637363ull);
-        h = hash_bytes(i, (size_t)nnz * sizeof(int32_t), h);
+    if (nnz > 0 && (!i || !x)) return fail(VBNMF_ERR_BAD_ARG, "a CSC slot pointer is NULL");
+    uint64_t h = 0, h2 = 0;
+    if (cache) {
+        h = hash_bytes(i, (size_t)nnz * sizeof(int32_t), 0x637363ull);
         h = hash_bytes(x, (size_t)nnz * sizeof(double), h);
+        h2 = hash_bytes(i, (size_t)nnz * sizeof(int32_t), 0x3243F6A8885A308Dull);
+        h2 = hash_bytes(x, (size_t)nnz * sizeof(double), h2);
     }
     if (!cache) C.drop();
     vbnmf_engine *e = nullptr;
-    int rc = stateless_engine(1, n, m, nnz, h, r, [&](vbnmf_matrix **M) { return vbnmf_matrix_from_csc(n, m, p, i, x, M); }, &e);
+    int rc = stateless_engine(1, n, m, nnz, h, h2, p, r, [&](vbnmf_matrix **M) { return vbnmf_matrix_from_csc(n, m, p, i, x, M); }, &e);
     if (!rc) rc = use(e);
     if (!cache || rc) C.drop();
     return rc;

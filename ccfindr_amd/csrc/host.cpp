@@ -354,7 +354,8 @@ LayoutParams default_layout_params(int64_t n_major, int64_t n_minor, int R, int 
 int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const LayoutParams &lp, Layout &L)
 {
     if (cb < 0 || ce > X.m || cb >= ce) return fail(VBNMF_ERR_BAD_ARG, "column range [%lld, %lld) is outside the matrix", (long long)cb, (long long)ce);
-    if (lp.block_width <= 0 || lp.block_width > 65536 || lp.max_len <= 0 || lp.max_len % kWidthQuantum || lp.n_wg <= 0 || lp.row_slots <= 0 ||
+    // (max_len <= 0x7FF8: the two leading-stretch lengths of a slice share one int32, 15 + 16 bits -- slice_fast below)
+    if (lp.block_width <= 0 || lp.block_width > 65536 || lp.max_len <= 0 || lp.max_len > 0x7FF8 || lp.max_len % kWidthQuantum || lp.n_wg <= 0 || lp.row_slots <= 0 ||
         (int64_t)std::max(lp.block_width, lp.block_cap) * lp.row_slots > (int64_t)(kPackedOffsetMask >> 4) + 1)
         return fail(VBNMF_ERR_BAD_ARG, "bad layout parameters");
 
@@ -557,8 +558,8 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
                 f = std::min(f, task_n1[(size_t)s * kLanes + l]);
                 f12 = std::min(f12, task_n1[(size_t)s * kLanes + l] + task_n2[(size_t)s * kLanes + l]);
             }
-            const int32_t f1 = f / 8 * 8;                        // whole loop trips (8 entries)
-            const int32_t f2 = std::min<int32_t>(std::max(f1, f12 / 8 * 8), 0xFFF8);
+            const int32_t f1 = std::min<int32_t>(f / 8 * 8, 0x7FF8);   // whole loop trips (8 entries)
+            const int32_t f2 = std::min<int32_t>(std::max(f1, f12 / 8 * 8), 0x7FF8);      // (sign bit of the word stays clear)
             L.slice_fast[s] = f1 | (f2 << 16);                   // low half: the stretch of ones; high half: of ones and twos
         }
     }

@@ -139,24 +139,42 @@ __global__ void k_label_pairs(const unsigned long long *__restrict__ table, int 
 
 // ---------------------------------------------------------------- dense pieces of the truncated SVD
 constexpr int kGramBlocks = 256;
-// Block partials of G = t(A) A for a tall A[N][R]: gp[block][R*R].  Thread (i, j) of a 32 x 32 block (R <= 32).
+// Block partials of G = t(A) A for a tall A[N][R]: gp[block][R*R].  Thread (i, j) of a 32 x 32 block owns the elements
+// (i + 32 a, j + 32 b) of G, a, b < ceil(R / 32): one element up to R = 32, four at the padded ranks 40..64.
 template <int R>
 __global__ __launch_bounds__(1024) void k_gram(const double *__restrict__ A, int64_t N, double *__restrict__ gp)
 {
+    constexpr int T = (R + 31) / 32;
     __shared__ double tile[32][R];
     const int i = threadIdx.x / 32, j = threadIdx.x % 32;
     const int64_t per = (N + gridDim.x - 1) / gridDim.x;
     const int64_t n0 = (int64_t)blockIdx.x * per, n1 = min(N, n0 + per);
-    double acc = 0.0;
-    for (int64_t b = n0; b < n1; b += 32) {
-        const int rows = (int)min((int64_t)32, n1 - b);
+    double acc[T][T];
+#pragma unroll
+    for (int a = 0; a < T; a++)
+#pragma unroll
+        for (int b = 0; b < T; b++) acc[a][b] = 0.0;
+    for (int64_t b0 = n0; b0 < n1; b0 += 32) {
+        const int rows = (int)min((int64_t)32, n1 - b0);
         __syncthreads();
-        for (int t = threadIdx.x; t < rows * R; t += 1024) tile[t / R][t % R] = A[(size_t)b * R + t];
+        for (int t = threadIdx.x; t < rows * R; t += 1024) tile[t / R][t % R] = A[(size_t)b0 * R + t];
         __syncthreads();
-        if (i < R && j < R)
-            for (int q = 0; q < rows; q++) acc = fma(tile[q][i], tile[q][j], acc);
+#pragma unroll
+        for (int a = 0; a < T; a++)
+#pragma unroll
+            for (int b = 0; b < T; b++) {
+                const int ii = i + 32 * a, jj = j + 32 * b;
+                if (ii < R && jj < R)
+                    for (int q = 0; q < rows; q++) acc[a][b] = fma(tile[q][ii], tile[q][jj], acc[a][b]);
+            }
     }
-    if (i < R && j < R) gp[(size_t)blockIdx.x * R * R + i * R + j] = acc;
+#pragma unroll
+    for (int a = 0; a < T; a++)
+#pragma unroll
+        for (int b = 0; b < T; b++) {
+            const int ii = i + 32 * a, jj = j + 32 * b;
+            if (ii < R && jj < R) gp[(size_t)blockIdx.x * R * R + ii * R + jj] = acc[a][b];
+        }
 }
 
 // One block.  G = sum of the block partials (fixed order), then, by `mode`:
@@ -173,15 +191,17 @@ __global__ __launch_bounds__(1024) void k_small(const double *__restrict__ gp, i
 {
     __shared__ double G[R][R + 1], V[R][R + 1];
     const int i = threadIdx.x / 32, j = threadIdx.x % 32;
-    if (i < R && j < R) {
-        double s = 0.0;
-        for (int b = 0; b < nb; b++) s += gp[(size_t)b * R * R + i * R + j];
-        G[i][j] = (i < k && j < k) ? s : (i == j ? 1.0 : 0.0);
-        V[i][j] = i == j ? 1.0 : 0.0;
-    }
+    // thread (i, j) of the 32 x 32 block owns the elements (i + 32 a, j + 32 b) of the R x R matrices (R up to 64)
+    for (int ii = i; ii < R; ii += 32)
+        for (int jj = j; jj < R; jj += 32) {
+            double s = 0.0;
+            for (int b = 0; b < nb; b++) s += gp[(size_t)b * R * R + ii * R + jj];
+            G[ii][jj] = (ii < k && jj < k) ? s : (ii == jj ? 1.0 : 0.0);
+            V[ii][jj] = ii == jj ? 1.0 : 0.0;
+        }
     __syncthreads();
     if (mode == 0) {
-        // Cholesky (upper) by thread 0 of each column step; k <= 32, sequential dependencies: one thread is enough
+        // Cholesky (upper) by thread 0 of each column step; k <= 64, sequential dependencies: one thread is enough
         if (threadIdx.x == 0) {
             int bad = 0;
             for (int c = 0; c < k; c++) {
@@ -212,10 +232,11 @@ __global__ __launch_bounds__(1024) void k_small(const double *__restrict__ gp, i
             for (int c = 0; c < k; c++) { vals[c] = V[c][c]; if (vals_host) vals_host[c] = V[c][c]; }
         }
         __syncthreads();
-        if (i < R && j < R) S[i * R + j] = G[i][j];
+        for (int ii = i; ii < R; ii += 32)
+            for (int jj = j; jj < R; jj += 32) S[ii * R + jj] = G[ii][jj];
         return;
     }
-    // cyclic Jacobi on the k x k symmetric G; rotations applied by the 32 lanes of row 0 of the block (lane j: column j)
+    // cyclic Jacobi on the k x k symmetric G; rotations applied by the 32 lanes of row 0 of the block (lane j: columns j, j + 32)
     __shared__ double off;
     for (int sweep = 0; sweep < 30; sweep++) {
         __syncthreads();
@@ -238,22 +259,24 @@ __global__ __launch_bounds__(1024) void k_small(const double *__restrict__ gp, i
                     c = 1.0 / sqrt(1.0 + t * t); s = t * c;
                 }
                 __syncthreads();
-                if (i == 0 && j < k) {                           // columns p, q of G and V: G <- G J, V <- V J
-                    const double gp_ = G[j][p], gq_ = G[j][q];
-                    G[j][p] = c * gp_ - s * gq_; G[j][q] = s * gp_ + c * gq_;
-                    const double vp = V[j][p], vq = V[j][q];
-                    V[j][p] = c * vp - s * vq; V[j][q] = s * vp + c * vq;
-                }
+                if (i == 0)
+                    for (int jj = j; jj < k; jj += 32) {         // columns p, q of G and V: G <- G J, V <- V J
+                        const double gp_ = G[jj][p], gq_ = G[jj][q];
+                        G[jj][p] = c * gp_ - s * gq_; G[jj][q] = s * gp_ + c * gq_;
+                        const double vp = V[jj][p], vq = V[jj][q];
+                        V[jj][p] = c * vp - s * vq; V[jj][q] = s * vp + c * vq;
+                    }
                 __syncthreads();
-                if (i == 0 && j < k) {                           // rows p, q of G: G <- t(J) G
-                    const double gp_ = G[p][j], gq_ = G[q][j];
-                    G[p][j] = c * gp_ - s * gq_; G[q][j] = s * gp_ + c * gq_;
-                }
+                if (i == 0)
+                    for (int jj = j; jj < k; jj += 32) {         // rows p, q of G: G <- t(J) G
+                        const double gp_ = G[p][jj], gq_ = G[q][jj];
+                        G[p][jj] = c * gp_ - s * gq_; G[q][jj] = s * gp_ + c * gq_;
+                    }
                 __syncthreads();
             }
     }
     __syncthreads();
-    // order the eigenvalues descending (thread 0: selection sort of k <= 32 columns)
+    // order the eigenvalues descending (thread 0: selection sort of k <= 64 columns)
     __shared__ int perm[R];
     if (threadIdx.x == 0) {
         for (int c = 0; c < R; c++) perm[c] = c;
@@ -266,11 +289,12 @@ __global__ __launch_bounds__(1024) void k_small(const double *__restrict__ gp, i
         if (vals_host) { __threadfence_system(); vals_host[R] = seq; }       // sequence number: the host sees a complete set
     }
     __syncthreads();
-    if (i < R && j < R) {
-        const double v = (i < k && j < k) ? V[i][perm[j]] : 0.0;
-        S[i * R + j] = v;
-        if (S2) { const double lam = j < k ? G[perm[j]][perm[j]] : 0.0; S2[i * R + j] = lam > 0.0 ? v / sqrt(lam) : 0.0; }
-    }
+    for (int ii = i; ii < R; ii += 32)
+        for (int jj = j; jj < R; jj += 32) {
+            const double v = (ii < k && jj < k) ? V[ii][perm[jj]] : 0.0;
+            S[ii * R + jj] = v;
+            if (S2) { const double lam = jj < k ? G[perm[jj]][perm[jj]] : 0.0; S2[ii * R + jj] = lam > 0.0 ? v / sqrt(lam) : 0.0; }
+        }
 }
 
 // B[N][R] = A[N][R] S (S: R x R row-major); in place allowed (a thread owns a whole row).

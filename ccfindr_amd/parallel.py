@@ -149,7 +149,9 @@ class CellPartitionedEngine:
             engine = VBEngine(X, rank, device=device, cols=self.cols, m_global=m)
         self.engine = engine
         if native is None:
-            native = (not injected) and (not inited or dist.get_backend(group) == "nccl")
+            # one process = no exchange: no communicator is built (a box without librccl can still run it) and the
+            # engine, unpartitioned, drives its own loop
+            native = (not injected) and self.world > 1 and dist.get_backend(group) == "nccl"
         self.native = bool(native)
         self.comm = None
         if self.native:
@@ -201,7 +203,7 @@ class CellPartitionedEngine:
     def run(self, hyper, **kw):
         """The device-driven loop of ``VBEngine.run`` across the partitions (native communicator only): every
         process calls it with the same arguments and gets the same result."""
-        if not self.native:
+        if not self.native and not (self.world == 1 and hasattr(self.engine, "run") and self.m == self.m_global):
             raise RuntimeError("the device-driven loop of a partitioned run needs the native (RCCL) communicator")
         return self.engine.run(hyper, **kw)
 

@@ -396,6 +396,12 @@ void vbnmf_layout_destroy(vbnmf_layout *L);
  * --------------------------------------------------------------------------------- */
 int vbnmf_test_special_host(int32_t kind, int64_t n, const double *x, double *y);
 int vbnmf_test_special_device(int32_t kind, int64_t n, const double *x, double *y);
+/* Test hook for the bounded waits: enqueues a host function that sleeps `seconds` (<= 60) on the engine's stream, so
+ * the steps queued behind it are late without the GPU being busy.  The waits of vbnmf_engine_step / _run / _ml_run are
+ * bounded by VBNMF_WAIT_TIMEOUT_S (seconds of wall clock, default 300): past it the call returns VBNMF_ERR_HIP with a
+ * message naming the last completed step, and the engine is left untouched (its destroy neither waits nor frees while
+ * work is still queued).  The reference has no analogue: its call is synchronous CPU code (src/RcppExports.cpp:11-22). */
+int vbnmf_test_stream_sleep(vbnmf_engine *e, double seconds);
 
 #ifdef __cplusplus
 }

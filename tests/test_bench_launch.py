@@ -1,0 +1,49 @@
+"""bench.py --gpus N from a bare launch: the process (which has not touched the GPU) starts the N ranks under
+torch.distributed.run as a child, relays rank 0's JSON line and leaves with the children's status."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bare_launch_composes_the_torchrun_command(monkeypatch):
+    sys.path.insert(0, ROOT)
+    import bench
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+
+        class R:
+            returncode = 7
+        return R()
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "20", "--warmup", "5"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as ei:
+        bench.main()
+    assert ei.value.code == 7                                # the children's status is the exit status
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=4" in cmd and "--master-addr" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "20", "--warmup", "5"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+@pytest.mark.gpu
+def test_bare_launch_two_ranks_on_one_gpu_prints_one_json_line():
+    env = dict(os.environ, BENCH_BACKEND="gloo", BENCH_ONE_DEVICE="1")
+    env.pop("WORLD_SIZE", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--small", "--steps", "5", "--warmup", "2",
+                        "--no-cpu", "--no-ml"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 5 and out["value"] > 0
+    assert "value_host_stepped" in out and out["warmup_effective"] >= 2 and "setup" in out

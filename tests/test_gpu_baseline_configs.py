@@ -131,10 +131,11 @@ def c3_matrix(c3):
     M.close()
 
 
-@pytest.mark.parametrize("r", [2, 5, 11, 15, 20])
+@pytest.mark.parametrize("r", [2, 4, 5, 8, 11, 14, 15, 18, 20])
 def test_config4_ranks_on_the_headline_matrix_against_sparse_oracle(c3_matrix, r):
-    """One resident step per rank on the full C3 matrix vs the oracle's stored-entries form.  The ranks cover every
-    geometry of the sweep kernel C4 uses: 1024 / 768 / 512 threads per workgroup (4 / 3 / 2 waves per SIMD), odd ranks
+    """One resident step per rank on the full C3 matrix vs the oracle's stored-entries form.  Ranks 2, 4, 5 (-> 6), 8,
+    11 (-> 12), 14, 15 (-> 16), 18, 20 plus the headline's 10 (test_config3) are EVERY padded rank, i.e. every template
+    instance of the sweep kernel C4 runs: 1024 / 768 / 512 threads per workgroup (4 / 3 / 2 waves per SIMD), odd ranks
     (padded column), and each LDS row size class."""
     import ccfindr_amd as C
     from ccfindr_amd import synth

@@ -81,7 +81,10 @@ def test_cell_partitioned_engine_over_rccl_world1():
         wh = synth.random_state(90, 140, 3, HY, seed=4)
         eng = parallel.CellPartitionedEngine(M, 3, device=0, native=False)
         eng.set_state(wh["lw"], wh["lh"], wh["eh"])
-        nat = parallel.CellPartitionedEngine(M, 3, device=0)
+        dflt = parallel.CellPartitionedEngine(M, 3, device=0)         # one process: no communicator by default
+        assert not dflt.native and dflt.comm is None
+        dflt.close()
+        nat = parallel.CellPartitionedEngine(M, 3, device=0, native=True)
         assert nat.native and nat.comm.kind == "rccl"
         nat.set_state(wh["lw"], wh["lh"], wh["eh"])
         ref = C.VBEngine(M, 3)

@@ -155,3 +155,24 @@ def test_device_svd_reports_a_rank_deficient_subspace():
     u, d, vt = truncated_svd(sp.csc_matrix(X), 2)
     D = np.linalg.svd(X, compute_uv=False)
     assert np.max(np.abs(d / D[:2] - 1)) <= 1e-9
+
+
+@pytest.mark.parametrize("k_engine,rank_out", [(40, 6), (48, 38), (64, 30)])
+def test_device_svd_above_32_subspace_columns_with_no_fallback(k_engine, rank_out):
+    """vbnmf_engine_svd called DIRECTLY with a subspace of 40 / 48 / 64 columns (the svd / svd2 initialisers at rank >= 23
+    use k = rank + 10): the Gram, Cholesky, Jacobi and write-out kernels tile their 32 x 32 thread grid over the k x k
+    matrices (csrc/init.h).  No host-QR fallback can satisfy this test: the triplets come from eng.svd() itself."""
+    import ccfindr_amd as C
+    n, m = 700, 900
+    X = planted(n, m, 12, seed=5)                      # 12 strong components over full-rank Poisson noise
+    eng = C.VBEngine(C.CountMatrix(sp.csc_matrix(X)), k_engine)
+    u, d, vt, its = eng.svd(rank_out, tol=1e-7, maxit=100, seed=1)
+    eng.close()
+    U, D, Vt = np.linalg.svd(X, full_matrices=False)
+    lead = 6                                            # a numpy model of the same iteration: values 2e-14, residuals 1e-7
+    assert np.max(np.abs(d[:lead] / D[:lead] - 1)) <= 1e-9, (d[:lead], D[:lead])
+    assert np.all(np.diff(d) <= 1e-12 * d[0])           # descending
+    assert np.allclose(u.T @ u, np.eye(rank_out), atol=1e-9) and np.allclose(vt @ vt.T, np.eye(rank_out), atol=1e-9)
+    # each returned triplet is a singular triplet of X to the iteration's accuracy: X v = d u
+    resid = np.linalg.norm(X @ vt.T - u * d, axis=0) / D[0]
+    assert np.max(resid[:lead]) <= 1e-5, resid[:lead]
