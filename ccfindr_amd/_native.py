@@ -65,6 +65,7 @@ SIGNATURES = {
     "vbnmf_matrix_csc": (ctypes.c_int, [_VP, ctypes.POINTER(c_int64_p), ctypes.POINTER(c_int32_p), ctypes.POINTER(c_double_p)]),
     "vbnmf_matrix_info": (ctypes.c_int, [_VP, c_int64_p, c_int64_p, c_int64_p, c_double_p]),
     "vbnmf_matrix_empty_counts": (ctypes.c_int, [_VP, c_int64_p, c_int64_p]),
+    "vbnmf_matrix_plan_ranks": (ctypes.c_int, [_VP, c_int32_p, _I32, _I32]),
     "vbnmf_matrix_destroy": (None, [_VP]),
     "vbnmf_engine_create": (ctypes.c_int, [_VP, _I32, _I32, _VPP]),
     "vbnmf_engine_create_part": (ctypes.c_int, [_VP, _I64, _I64, _I64, _I32, _I32, _VPP]),

@@ -409,11 +409,25 @@ def make_bundle(mat, ranks, nrun, verbose, initializer, Itmax, hyper_update, gam
             "seed": seed, "device": device, "engine_factory": engine_factory}
 
 
+def plan_geometry(bundle, geometry_classes=1):
+    """A sweep over several ranks shares ONE pair of tiled layouts (``CountMatrix.plan_ranks``): the geometry of the
+    largest rank (``geometry_classes`` = 1), or up to that many classes.  Cutting a pair per LDS row size cost the
+    reference-default sweep of BASELINE config C4 (ranks 2..20) 5 s of host time against 0.3 s of stepping; the price is
+    a somewhat slower step at the lower ranks (narrower LDS blocks than their rows would allow).  0 = every rank its own
+    geometry.  Returns True when a plan was set (the caller clears it afterwards)."""
+    X = bundle["mat"]
+    ranks = sorted({int(r) for r in bundle["ranks"]})
+    if geometry_classes and len(ranks) > 1 and hasattr(X, "plan_ranks"):
+        X.plan_ranks(ranks, geometry_classes)
+        return True
+    return False
+
+
 def vb_factorize(mat, ranks=2, nrun=1, verbose=2, progress_bar=True, initializer="random", Itmax=10000,
                  hyper_update=(True, True, True, True), gamma_a=1, gamma_b=1, Tol=1e-5,
                  hyper_update_n0=10, hyper_update_dn=1, connectivity=False, fudge=None, ncores=1,
                  useC=True, unif_stop=True, seed=None, device=0, engine_factory=None, device_loop=True, concurrent=1,
-                 device_init=False):
+                 device_init=False, geometry_classes=1):
     """Bayesian NMF of a count matrix on the MI355X engine; reference R/bayesian.R:229-301.
 
     ``mat`` is the genes x cells count matrix (dense, scipy sparse, or ``CountMatrix``).
@@ -431,6 +445,7 @@ def vb_factorize(mat, ranks=2, nrun=1, verbose=2, progress_bar=True, initializer
     ``device_init`` draws the ``random`` initial state on the GPU (``vbnmf_engine_random_state``: Philox counters +
     Marsaglia-Tsang, one key per (seed, run, rank)) instead of with numpy on the host; off by default so that runs
     with an injected engine and runs on the HIP engine start from the same arrays.
+    ``geometry_classes``: see ``plan_geometry`` (several ranks share the tiled layouts of the largest one; 0 = off).
     """
     del progress_bar, useC, ncores
     if connectivity:
@@ -441,6 +456,7 @@ def vb_factorize(mat, ranks=2, nrun=1, verbose=2, progress_bar=True, initializer
     bundle["device_init"] = bool(device_init)
     bundle["concurrent"] = max(1, int(concurrent))
     bundle["engines"] = {} if (nrun > 1 or bundle["concurrent"] > 1) else None   # restarts of a rank reuse its engine
+    planned = plan_geometry(bundle, geometry_classes)
     try:
         if bundle["concurrent"] > 1:
             from concurrent.futures import ThreadPoolExecutor
@@ -455,4 +471,6 @@ def vb_factorize(mat, ranks=2, nrun=1, verbose=2, progress_bar=True, initializer
             vb = [vb_iterate(irun, bundle) for irun in range(1, nrun + 1)]       # :260-261
     finally:
         _close_engines(bundle)
+        if planned:
+            bundle["mat"].plan_ranks(())
     return select_best(vb, bundle["ranks"])

@@ -77,6 +77,18 @@ constexpr int kPackedCountShift = 18;
 constexpr uint32_t kPackedOffsetMask = 0x3FFF0u;
 constexpr double kPackedCountMax = 16383.0;
 
+// std::allocator whose resize() leaves trivially constructible elements uninitialised (no zero-fill pass over the
+// 200 MB entry arrays: the builder writes every slot itself).
+template <class T>
+struct NoInitAlloc : std::allocator<T> {
+    template <class U> struct rebind { using other = NoInitAlloc<U>; };
+    NoInitAlloc() = default;
+    template <class U> NoInitAlloc(const NoInitAlloc<U> &) {}
+    template <class U> void construct(U *p) noexcept { ::new (static_cast<void *>(p)) U; }
+    template <class U, class... A> void construct(U *p, A &&...a) { ::new (static_cast<void *>(p)) U(std::forward<A>(a)...); }
+};
+template <class T> using BigVec = std::vector<T, NoInitAlloc<T>>;
+
 struct Layout {
     int side = 0;                   // 0: lanes own genes, minors = cells; 1: lanes own cells, minors = genes
     bool wide = false;
@@ -94,9 +106,9 @@ struct Layout {
     std::vector<int32_t> seg_ptr;        // n_segs + 1 : first slice of each segment
     std::vector<int32_t> inv_ptr;        // n_major + 1 : tasks of each major ...
     std::vector<uint32_t> inv_task;      // n_tasks     : ... as slice*64+lane ids, in (block, position) order
-    std::vector<uint32_t> packed;        // n_slots (wide == false)
-    std::vector<uint32_t> wide_idx;      // n_slots (wide == true)
-    std::vector<double> wide_val;        // n_slots (wide == true)
+    BigVec<uint32_t> packed;             // n_slots (wide == false)
+    BigVec<uint32_t> wide_idx;           // n_slots (wide == true)
+    BigVec<double> wide_val;             // n_slots (wide == true)
 };
 
 struct LayoutParams {
@@ -184,6 +196,13 @@ struct vbnmf_matrix {
     vbnmf::Matrix M;
     double lgx = 0.0;      // sum over stored entries of lgamma(x+1)
     mutable LayoutCache layouts;
+    // Rank classes (vbnmf_matrix_plan_ranks): padded ranks, ascending.  An engine of padded rank R on this matrix takes the
+    // geometry (LDS block width, row stride) of the smallest class >= R -- its own when there is none.
+    mutable std::mutex plan_mu;
+    mutable std::vector<int32_t> plan;
+    // sum over stored entries of -x log x + x, formed once (whole matrix; ML-NMF likelihood constant)
+    mutable std::once_flag xlx_once;
+    mutable double xlx = 0.0;
 };
 namespace vbnmf {
 // The layout of `side` for the whole matrix at the default geometry of padded rank R: from the matrix's cache, or
@@ -192,6 +211,8 @@ std::shared_ptr<const Layout> shared_layout(const vbnmf_matrix *X, int side, con
 // Device copies of cached layouts: look one up (null if absent) / remember one (ignored if the layout is not cached).
 std::shared_ptr<void> cached_device_copy(const vbnmf_matrix *X, const Layout *L, int device);
 void store_device_copy(const vbnmf_matrix *X, const Layout *L, int device, std::shared_ptr<void> arrays);
+// The padded rank whose geometry an engine of padded rank R uses on this matrix (R itself without a plan).
+int plan_class(const vbnmf_matrix *X, int R);
 }
 struct vbnmf_layout {
     vbnmf::Layout L;

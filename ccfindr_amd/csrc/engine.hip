@@ -74,7 +74,7 @@ struct DeviceSide {
     int64_t *slice_off = nullptr;
     double *part = nullptr;                    // this engine's per-task partial statistics
     int64_t n_major = 0, n_minor = 0, n_tasks = 0, n_slices = 0, n_slots = 0;
-    int32_t block_width = 0, n_blocks = 0, n_wg = 0;
+    int32_t block_width = 0, n_blocks = 0, n_wg = 0, row_slots = 0;
     bool wide = false;
 };
 
@@ -89,8 +89,8 @@ int dev_alloc(T **p, size_t count)
     return VBNMF_OK;
 }
 
-template <typename T>
-int dev_upload(T **p, const std::vector<T> &v)
+template <typename T, typename A>
+int dev_upload(T **p, const std::vector<T, A> &v)
 {
     if (int rc = dev_alloc(p, v.size())) return rc;
     if (!v.empty()) HIPCHECK(hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
@@ -166,6 +166,9 @@ int upload_side(const Layout &L, int R, int device, const vbnmf_matrix *X, Devic
 {
     S.n_major = L.n_major; S.n_minor = L.n_minor; S.n_tasks = L.n_tasks; S.n_slices = L.n_slices;
     S.n_slots = L.n_slots; S.block_width = L.block_width; S.n_blocks = L.n_blocks; S.n_wg = L.n_wg; S.wide = L.wide;
+    S.row_slots = L.row_slots;
+    if (S.row_slots < R / 2 / rank_shares(R) * rank_shares(R) || !(S.row_slots & 1))
+        return fail(VBNMF_ERR_BAD_ARG, "layout row stride of %d slots cannot hold rows of padded rank %d", S.row_slots, R);
     std::shared_ptr<DeviceArrays> A;
     if (X) A = std::static_pointer_cast<DeviceArrays>(cached_device_copy(X, &L, device));
     if (!A) {
@@ -211,6 +214,7 @@ SweepSide sweep_side_args(const vbnmf_engine *e, const DeviceSide &S, bool gene_
     P.G = gene_side ? e->lh : e->lw;
     P.part = S.part; P.epart = epart;
     P.n_minor = (int32_t)S.n_minor; P.block_start = S.block_start;
+    P.row_slots = S.row_slots;
     P.logterm = gene_side ? 1 : 0;
     P.n_wg = S.n_wg;
     P.logtab = e->logtab;
@@ -656,7 +660,10 @@ int vbnmf_engine_create_part(const vbnmf_matrix *X, int64_t cb, int64_t ce, int6
     try {
         for (int side = 0; side < 2 && !rc; side++) {
             int64_t nmaj = side == 0 ? e->n : e->m, nmin = side == 0 ? e->m : e->n;
-            LayoutParams lp = default_layout_params(nmaj, nmin, e->R, e->n_wg, X->M.colptr[ce] - X->M.colptr[cb]);
+            // The geometry is that of the matrix's rank CLASS (vbnmf_matrix_plan_ranks; without a plan the class is this
+            // rank's own): the ranks of a sweep share one pair of layouts, cut for the widest rows among them.
+            const int Rc = std::max(e->R, plan_class(X, e->R));
+            LayoutParams lp = default_layout_params(nmaj, nmin, Rc, e->n_wg, X->M.colptr[ce] - X->M.colptr[cb]);
             std::shared_ptr<const Layout> shared;
             Layout own;
             const Layout *L = &own;
@@ -674,9 +681,15 @@ int vbnmf_engine_create_part(const vbnmf_matrix *X, int64_t cb, int64_t ce, int6
     }
     if (rc) return bail(rc);
     e->lgx = (cb == 0 && ce == X->M.m) ? X->lgx : sum_lgamma_x1(X->M, cb, ce);
-    e->xlx = sum_xlogx(X->M, cb, ce);
+    if (cb == 0 && ce == X->M.m) {                    // whole matrix: formed once per matrix, not per engine (a pass over X)
+        std::call_once(X->xlx_once, [&] { X->xlx = sum_xlogx(X->M, 0, X->M.m); });
+        e->xlx = X->xlx;
+    } else {
+        e->xlx = sum_xlogx(X->M, cb, ce);
+    }
     static_assert(kLdsRowBase == kLdsReserveBytes, "host and device disagree on the sweep's LDS reserve");
-    e->lds_bytes = kLdsRowBase + (size_t)std::max(e->A.block_width, e->B.block_width) * lds_row_bytes(e->R);
+    e->lds_bytes = kLdsRowBase + std::max((size_t)e->A.block_width * e->A.row_slots, (size_t)e->B.block_width * e->B.row_slots) * 16;
+    if (e->lds_bytes > 160 * 1024) return bail(fail(VBNMF_ERR_BAD_ARG, "the layout's blocks need %zu bytes of LDS", e->lds_bytes));
     {
         std::vector<LogTabEntry> tab(kLogTabSize);
         fill_log_table(tab.data());

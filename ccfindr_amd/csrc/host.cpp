@@ -7,6 +7,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <atomic>
 #include <sched.h>
 
 #include <chrono>
@@ -735,118 +736,147 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
     lap("inverse");
 
     try {
-        if (L.wide) { L.wide_idx.assign(L.n_slots, 0u); L.wide_val.assign(L.n_slots, 0.0); }
-        else L.packed.assign(L.n_slots, 0u);
+        // not zero-filled (the fill below writes every slot, padding included: first touch by the thread that fills)
+        if (L.wide) { L.wide_idx.resize(L.n_slots); L.wide_val.resize(L.n_slots); }
+        else L.packed.resize(L.n_slots);
     } catch (const std::bad_alloc &) {
         return fail(VBNMF_ERR_OOM, "out of host memory building the tiled layout (%lld slots)", (long long)L.n_slots);
     }
 
-    // fill: slot(t, lane) = off + (t/4)*256 + lane*4 + t%4 ; padding slots stay {minor 0, value 0}.
+    // fill: slot(t, lane) = off + (t/4)*256 + lane*4 + t%4 ; padding slots are {minor 0, value 0}.
     //
     // The order of a task's entries is free (it only fixes the summation order), so it is chosen
     // to keep the LDS gathers of the sweep conflict-free: a ds_read_b128 wave instruction is served
     // in four fixed groups of 16 lanes, one LDS cycle per group when the 16 addresses fall in 16
     // different 16-byte bank slots.  Rows of the staged factor are an odd number of slots long, so
     // the slot of piece p of row `local` is (stride*local + p) mod 16: two lanes of a group collide
-    // exactly when their minors are congruent mod 16.  Step by step, each group therefore hands out
-    // distinct residues (local mod 16) to its lanes: residues in order of remaining demand, each to
-    // the lane with the fewest other residues left; a lane that finds all its residues taken
-    // doubles up on the least used one.
+    // exactly when their minors are congruent mod 16.  Step by step, the 16 lanes of a group choose in
+    // turn (the turn order rotates with the step): a lane takes, among the residues (local mod 16) it
+    // still has entries of and no earlier lane of this step took, the one it has most of; a lane that
+    // finds all its residues taken doubles up on the least used one.  Round 2 chose residue by residue
+    // (demand order, each to the lane with the fewest other residues left): twice the inner work plus
+    // a sort per step -- 85 % of the layout's build time -- for conflict rates this scheme undercuts
+    // (LDS cycles per group read on the headline matrix, gene / cell side: 1.70 / 1.86 then, 1.66 / 1.83 now).
     lap("alloc");
     static const int kGroupOf[64] = {0,0,0,0,1,1,1,1,1,1,1,1,0,0,0,0,1,1,1,1,0,0,0,0,0,0,0,0,1,1,1,1,
                                      2,2,2,2,3,3,3,3,3,3,3,3,2,2,2,2,3,3,3,3,2,2,2,2,2,2,2,2,3,3,3,3};
     const bool schedule = env_int("VBNMF_NO_BANK_SCHEDULE", 0) == 0;
-    parallel_for(L.n_slices, [&](int64_t b, int64_t e, int) {
-        // [phase][lane in group][residue] -> stack of positions; phase 0 = the task's entries of value 1 (placed
-        // first, see above), phase 1 = those of value 2, phase 2 = the others (every entry when the fast stretch is off)
+    // Slices differ in cost by two orders of magnitude and lie sorted by width inside a segment: small chunks
+    // handed out through a shared counter, not one contiguous range per thread.
+    std::atomic<int64_t> next_chunk{0};
+    const int64_t kChunk = 16;
+    parallel_for(host_threads(), [&](int64_t, int64_t, int) {
+        // phase 0 = the task's entries of value 1 (placed first, see above), 1 = those of value 2, 2 = the others
+        // (every entry when the fast stretch is off)
         constexpr int NP = 3;
-        std::vector<int32_t> bucket[NP][16][16];
-        for (int64_t s = b; s < e; s++) {
+        std::vector<int32_t> sorted[16];                   // per lane of the group: entry positions by (phase, residue, minor)
+        std::vector<uint8_t> bucket_of;                    // (phase, residue) of every entry of the task at hand
+        for (;;) {
+        const int64_t c0 = next_chunk.fetch_add(kChunk);
+        if (c0 >= L.n_slices) break;
+        for (int64_t s = c0; s < std::min<int64_t>(L.n_slices, c0 + kChunk); s++) {
             const int32_t m0 = (int32_t)bstart[L.slice_block[s]];
             const int64_t so = L.slice_off[s];
+            const int32_t width = L.slice_width[s];
             auto put = [&](int lane, int64_t t, int64_t q) {
                 int64_t slot = so + (t / kUnroll) * (kLanes * kUnroll) + lane * kUnroll + (t % kUnroll);
                 uint32_t local = (uint32_t)(idx[q] - m0);
                 if (L.wide) { L.wide_idx[slot] = local; L.wide_val[slot] = val[q]; }
                 else L.packed[slot] = ((uint32_t)val[q] << kPackedCountShift) | ((local * (uint32_t)L.row_slots) << 4);
             };
+            auto pad = [&](int lane, int64_t t0) {         // the arrays are not zero-filled at allocation: the tail of every lane is
+                for (int64_t t = t0; t < width; t++) {
+                    int64_t slot = so + (t / kUnroll) * (kLanes * kUnroll) + lane * kUnroll + (t % kUnroll);
+                    if (L.wide) { L.wide_idx[slot] = 0u; L.wide_val[slot] = 0.0; } else L.packed[slot] = 0u;
+                }
+            };
             auto phase_of = [&](int64_t q) { return !fast_ones ? 2 : (val[q] == 1.0 ? 0 : (val[q] == 2.0 ? 1 : 2)); };
             if (!schedule) {
                 for (int lane = 0; lane < kLanes; lane++) {
                     size_t id = (size_t)s * kLanes + lane;
-                    if (L.task_major[id] == kIdleLane) continue;
                     int64_t t = 0;
-                    for (int ph = 0; ph < NP; ph++)
-                        for (int64_t u = 0; u < task_len[id]; u++)
-                            if (phase_of(task_pos[id] + u) == ph) put(lane, t++, task_pos[id] + u);
+                    if (L.task_major[id] != kIdleLane)
+                        for (int ph = 0; ph < NP; ph++)
+                            for (int64_t u = 0; u < task_len[id]; u++)
+                                if (phase_of(task_pos[id] + u) == ph) put(lane, t++, task_pos[id] + u);
+                    pad(lane, t);
                 }
                 continue;
             }
             for (int g = 0; g < 4; g++) {
                 int lanes[16], nl = 0;
                 for (int lane = 0; lane < kLanes; lane++) if (kGroupOf[lane] == g) lanes[nl++] = lane;
-                int cnt[NP][16][16] = {}, rem[NP][16] = {}, step[16] = {}, dem[16] = {}, nopt[NP][16] = {};
-                auto cur = [&](int j) { return rem[0][j] > 0 ? 0 : (rem[1][j] > 0 ? 1 : 2); };        // the phase lane j is in
+                // key[lane][phase][residue] = (entries left << 4) | (15 - residue): the largest key among a lane's candidates is
+                // "most entries left, ties to the lowest residue" in one comparison
+                uint32_t key[16][NP][16];
+                int32_t nxt[16][NP][16];                   // where the next entry of that bucket sits in sorted[lane]
+                uint16_t avail[16][NP] = {};               // residues with entries left, as a bit mask
+                int32_t rem[16][NP] = {}, step[16] = {};
+                int64_t base[16];
                 int T = 0;
                 for (int j = 0; j < 16; j++) {
-                    for (int ph = 0; ph < NP; ph++) for (int r = 0; r < 16; r++) bucket[ph][j][r].clear();
-                    size_t id = (size_t)s * kLanes + lanes[j];
+                    const size_t id = (size_t)s * kLanes + lanes[j];
+                    base[j] = 0;
                     if (L.task_major[id] == kIdleLane) continue;
                     const int64_t q0 = task_pos[id];
-                    for (int32_t t = task_len[id] - 1; t >= 0; t--) {      // reversed: stacks pop in ascending minor order
-                        const int ph = phase_of(q0 + t);
-                        int r = (idx[q0 + t] - m0) & 15;
-                        bucket[ph][j][r].push_back(t);
-                        if (cnt[ph][j][r]++ == 0) nopt[ph][j]++;      // nopt: residues the lane still has entries of, per phase
-                        rem[ph][j]++;
+                    const int32_t len = task_len[id];
+                    base[j] = q0;
+                    bucket_of.resize(len);
+                    int32_t cnt[NP * 16] = {};
+                    for (int32_t t = 0; t < len; t++) {    // one pass over the task: phase and residue of every entry
+                        const int b = phase_of(q0 + t) * 16 + ((idx[q0 + t] - m0) & 15);
+                        bucket_of[t] = (uint8_t)b;
+                        cnt[b]++;
                     }
-                    for (int r = 0; r < 16; r++) dem[r] += cnt[cur(j)][j][r];   // demand of the lanes' CURRENT phases
-                    T = std::max(T, rem[0][j] + rem[1][j] + rem[2][j]);
+                    int32_t o = 0, w[NP * 16];
+                    for (int ph = 0; ph < NP; ph++)
+                        for (int r = 0; r < 16; r++) {
+                            const int32_t c = cnt[ph * 16 + r];
+                            nxt[j][ph][r] = o; w[ph * 16 + r] = o; o += c;
+                            rem[j][ph] += c;
+                            key[j][ph][r] = ((uint32_t)c << 4) | (uint32_t)(15 - r);
+                            if (c) avail[j][ph] |= (uint16_t)(1u << r);
+                        }
+                    sorted[j].resize(len);
+                    for (int32_t t = 0; t < len; t++)      // stable: a bucket keeps its entries in ascending minor order
+                        sorted[j][w[bucket_of[t]]++] = t;
+                    T = std::max(T, len);
                 }
                 for (int t = 0; t < T; t++) {
-                    int used[16] = {};
-                    bool assigned[16] = {};
-                    int ord[16];
-                    for (int r = 0; r < 16; r++) ord[r] = r;
-                    std::stable_sort(ord, ord + 16, [&](int x, int y) { return dem[x] > dem[y]; });
-                    auto take = [&](int j, int r) {
-                        size_t id = (size_t)s * kLanes + lanes[j];
-                        const int ph = cur(j);
-                        int32_t tt = bucket[ph][j][r].back();
-                        bucket[ph][j][r].pop_back();
-                        put(lanes[j], step[j]++, task_pos[id] + tt);
-                        assigned[j] = true; used[r]++; dem[r]--; rem[ph][j]--;
-                        if (--cnt[ph][j][r] == 0) nopt[ph][j]--;
-                        if (ph < NP - 1 && rem[ph][j] == 0) {                 // the lane moves on to its next kind of entries
-                            const int nx = cur(j);
-                            if (nx != ph && rem[nx][j] > 0) for (int q = 0; q < 16; q++) dem[q] += cnt[nx][j][q];
+                    uint32_t used = 0;                     // residues taken in this step
+                    uint8_t usedcnt[16] = {};
+                    for (int q = 0; q < 16; q++) {
+                        const int j = (t + q) & 15;
+                        const int ph = rem[j][0] > 0 ? 0 : (rem[j][1] > 0 ? 1 : 2);
+                        if (rem[j][ph] == 0) continue;
+                        const uint32_t *k = key[j][ph];
+                        uint32_t cand = avail[j][ph] & ~used;
+                        int best;
+                        if (cand) {
+                            uint32_t bk = 0;
+                            best = 0;
+                            while (cand) {
+                                const int r = __builtin_ctz(cand);
+                                cand &= cand - 1;
+                                if (k[r] > bk) { bk = k[r]; best = r; }
+                            }
+                        } else {                           // every residue it has is taken: the least used, then the fullest, then the lowest
+                            best = -1;
+                            for (uint32_t a = avail[j][ph]; a; a &= a - 1) {
+                                const int r = __builtin_ctz(a);
+                                if (best < 0 || usedcnt[r] < usedcnt[best] || (usedcnt[r] == usedcnt[best] && k[r] > k[best])) best = r;
+                            }
                         }
-                    };
-                    for (int oi = 0; oi < 16; oi++) {
-                        const int r = ord[oi];
-                        if (dem[r] == 0) break;
-                        int best = -1, best_opt = 99, best_cnt = -1;
-                        for (int j = 0; j < 16; j++) {
-                            if (assigned[j]) continue;
-                            const int ph = cur(j);
-                            if (rem[ph][j] == 0 || cnt[ph][j][r] == 0) continue;
-                            if (nopt[ph][j] < best_opt || (nopt[ph][j] == best_opt && cnt[ph][j][r] > best_cnt)) { best = j; best_opt = nopt[ph][j]; best_cnt = cnt[ph][j][r]; }
-                        }
-                        if (best >= 0) take(best, r);
-                    }
-                    for (int j = 0; j < 16; j++) {
-                        if (assigned[j]) continue;
-                        const int ph = cur(j);
-                        if (rem[ph][j] == 0) continue;
-                        int best = -1;
-                        for (int r = 0; r < 16; r++) {
-                            if (cnt[ph][j][r] == 0) continue;
-                            if (best < 0 || used[r] < used[best] || (used[r] == used[best] && dem[r] > dem[best])) best = r;
-                        }
-                        take(j, best);
+                        put(lanes[j], step[j]++, base[j] + sorted[j][nxt[j][ph][best]++]);
+                        used |= 1u << best; usedcnt[best]++;
+                        rem[j][ph]--;
+                        key[j][ph][best] -= 16;
+                        if ((key[j][ph][best] >> 4) == 0) avail[j][ph] &= (uint16_t)~(1u << best);
                     }
                 }
+                for (int j = 0; j < 16; j++) pad(lanes[j], step[j]);
             }
+        }
         }
     });
     lap("fill");
@@ -886,6 +916,13 @@ std::shared_ptr<const Layout> shared_layout(const vbnmf_matrix *X, int side, con
         }
     }
     return L;
+}
+
+int plan_class(const vbnmf_matrix *X, int R)
+{
+    std::lock_guard<std::mutex> g(X->plan_mu);
+    for (int32_t c : X->plan) if (c >= R) return c;
+    return R;
 }
 
 std::shared_ptr<void> cached_device_copy(const vbnmf_matrix *X, const Layout *L, int device)
@@ -998,6 +1035,42 @@ int vbnmf_matrix_empty_counts(const vbnmf_matrix *X, int64_t *empty_rows, int64_
     for (double v : rs) er += (v == 0.0);
     if (empty_rows) *empty_rows = er;
     if (empty_cols) *empty_cols = ec;
+    return VBNMF_OK;
+}
+
+// Rank classes of a sweep over several ranks (reference R/bayesian.R:316: `for(rank in ranks)`, every rank on the same
+// matrix).  The tiled layout depends on the rank only through the LDS row size; cutting one per row size costs more host
+// time than the whole sweep spends on the device (BASELINE config C4: six geometries, 5 s, against 0.3 s of stepping).
+// With a plan, every rank uses the geometry of the smallest class at or above it: narrower blocks than its own rows
+// would allow (more, shorter tasks: a slower step), but cut once.  max_classes = 1: one class at the largest rank;
+// k > 1: the k - 1 further classes halve the remaining range of row sizes each (largest first).  count = 0 clears it.
+int vbnmf_matrix_plan_ranks(vbnmf_matrix *X, const int32_t *ranks, int32_t count, int32_t max_classes)
+{
+    if (!X || (count > 0 && !ranks) || count < 0) return fail(VBNMF_ERR_BAD_ARG, "NULL argument");
+    std::vector<int32_t> padded;
+    for (int32_t q = 0; q < count; q++) {
+        if (ranks[q] < 1 || ranks[q] > VBNMF_MAX_RANK) return fail(VBNMF_ERR_BAD_ARG, "rank %d is outside [1, %d]", ranks[q], VBNMF_MAX_RANK);
+        padded.push_back(padded_rank(ranks[q]));
+    }
+    std::sort(padded.begin(), padded.end());
+    padded.erase(std::unique(padded.begin(), padded.end()), padded.end());
+    std::vector<int32_t> classes;
+    if (!padded.empty()) {
+        if (max_classes < 1) max_classes = 1;
+        int32_t top = padded.back();
+        classes.push_back(top);
+        while ((int32_t)classes.size() < max_classes) {
+            // the largest planned rank whose rows are at most half as wide as the current lowest class's
+            int32_t next = 0;
+            for (int32_t p : padded) if (lds_row_bytes(p) * 2 <= lds_row_bytes(top)) next = p;
+            if (!next) break;
+            classes.push_back(next);
+            top = next;
+        }
+        std::sort(classes.begin(), classes.end());
+    }
+    std::lock_guard<std::mutex> g(X->plan_mu);
+    X->plan.swap(classes);
     return VBNMF_OK;
 }
 

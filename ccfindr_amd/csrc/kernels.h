@@ -55,6 +55,8 @@ struct SweepSide {
     double *part;                  // [n_slices*64][R] partial statistics per task
     double *epart;                 // [n_wg] evidence partials, one per workgroup
     int32_t n_minor;
+    int32_t row_slots;             // LDS row stride of the staged factor block in 16-byte slots (odd; >= R / 2: the stride of the
+                                   // layout's rank class, which may be wider than this rank's own rows -- common.h, rank classes)
     int32_t logterm;               // this side also accumulates sum x*log(wth)
     int32_t n_wg;
     const LogTabEntry *logtab;     // [128] ln table (staged at the front of LDS)
@@ -259,7 +261,7 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
         __syncthreads();                                   // readers of the previous block are done
         if (threadIdx.x == 0) *ticket = 0;
         {
-            constexpr int kSlots = (RT / 2) | 1;           // LDS row stride in 16-byte slots (odd)
+            const int kSlots = S.row_slots;                // LDS row stride in 16-byte slots (odd)
             const double2 *G2 = reinterpret_cast<const double2 *>(S.G + (size_t)m0 * RT);
             const int cnt = cw * (RT / 2);
             double2 *rows = ldsG + kLdsRowBase / sizeof(double2);
@@ -398,15 +400,16 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
                 double2 g1[R / 2];
                 const uint4 *E = reinterpret_cast<const uint4 *>(S.widx + off) + tlane;
                 const double2 *V = reinterpret_cast<const double2 *>(S.wval + off) + tlane * 2;
+                const uint32_t rowb = (uint32_t)S.row_slots * 16u;     // bytes per staged row
                 for (int g = 0; g < ng; g++) {
                     const uint4 c = E[(size_t)g * 64];
                     const double2 v0 = V[(size_t)g * 128], v1 = V[(size_t)g * 128 + 1];
-                    lds_row<R>(ldsG, c.x * (((RT / 2) | 1) * 16) + share, g0);
-                    lds_row<R>(ldsG, c.y * (((RT / 2) | 1) * 16) + share, g1);
+                    lds_row<R>(ldsG, c.x * rowb + share, g0);
+                    lds_row<R>(ldsG, c.y * rowb + share, g1);
                     sweep_entry<R, EV == 3, false, SP>(T, ldsG, g0, v0.x, LOGTERM);
-                    lds_row<R>(ldsG, c.z * (((RT / 2) | 1) * 16) + share, g0);
+                    lds_row<R>(ldsG, c.z * rowb + share, g0);
                     sweep_entry<R, EV == 3, false, SP>(T, ldsG, g1, v0.y, LOGTERM);
-                    lds_row<R>(ldsG, c.w * (((RT / 2) | 1) * 16) + share, g1);
+                    lds_row<R>(ldsG, c.w * rowb + share, g1);
                     sweep_entry<R, EV == 3, false, SP>(T, ldsG, g0, v1.x, LOGTERM);
                     sweep_entry<R, EV == 3, false, SP>(T, ldsG, g1, v1.y, LOGTERM);
                 }

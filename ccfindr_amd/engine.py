@@ -112,6 +112,13 @@ class CountMatrix:
         N.check(self._lib.vbnmf_matrix_empty_counts(self._h, ctypes.byref(er), ctypes.byref(ec)))
         return er.value, ec.value
 
+    def plan_ranks(self, ranks=(), max_classes=1):
+        """Rank classes for a sweep over several ranks (vbnmf_matrix_plan_ranks): engines created afterwards share the
+        tiled layouts of the smallest class at or above their rank instead of cutting a pair per LDS row size.  An empty
+        ``ranks`` clears the plan."""
+        arr = np.asarray(list(ranks), dtype=np.int32)
+        N.check(self._lib.vbnmf_matrix_plan_ranks(self._h, arr.ctypes.data_as(N.c_int32_p), int(arr.size), int(max_classes)))
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
             self._lib.vbnmf_matrix_destroy(self._h)

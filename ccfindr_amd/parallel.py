@@ -19,7 +19,7 @@ import math
 
 import numpy as np
 
-from .bayesian import _close_engines, assemble_run, make_bundle, select_best, vb_run_rank
+from .bayesian import _close_engines, assemble_run, make_bundle, plan_geometry, select_best, vb_run_rank
 from .engine import EPS, VBEngine
 
 
@@ -53,7 +53,7 @@ def sweep_tasks(ranks, nrun):
 def vb_factorize_sharded(mat, ranks=2, nrun=1, verbose=0, initializer="random", Itmax=10000,
                          hyper_update=(True, True, True, True), gamma_a=1, gamma_b=1, Tol=1e-5,
                          hyper_update_n0=10, hyper_update_dn=1, fudge=None, unif_stop=True, seed=0,
-                         device=None, group=None, engine_factory=None):
+                         device=None, group=None, engine_factory=None, geometry_classes=1):
     """``vb_factorize`` with the (run, rank) units sharded over the ranks of a process group.
 
     Call it from every process (``torch.distributed`` initialised, one process per GPU).
@@ -73,6 +73,9 @@ def vb_factorize_sharded(mat, ranks=2, nrun=1, verbose=0, initializer="random", 
     tasks, costs = sweep_tasks(bundle["ranks"], nrun)
     mine = lpt_schedule(costs, world)[me]
     bundle["engines"] = {} if nrun > 1 else None        # this process's restarts of a rank share the engine
+    # the geometry plan covers ALL ranks of the sweep, not only this process's units: every process cuts the same
+    # layouts, so a unit's result does not depend on which process ran it (bit for bit, as vb_factorize's)
+    planned = plan_geometry(bundle, geometry_classes)
     # A unit that raises (hyper-parameter Newton failure, a VBNMFError, rank > min(nrow, ncol) ...) must not keep
     # this process from the gather below: the other processes would wait in it for ever.  The error travels as a
     # record, every process reaches the collective, and then every process raises the first error (by unit order).
@@ -86,6 +89,8 @@ def vb_factorize_sharded(mat, ranks=2, nrun=1, verbose=0, initializer="random", 
                 break
     finally:
         _close_engines(bundle)
+        if planned:
+            bundle["mat"].plan_ranks(())
     if world > 1:
         gathered = [None] * world
         dist.all_gather_object(gathered, (local, failure), group=group)   # control plane: host objects, once per sweep

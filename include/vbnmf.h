@@ -93,6 +93,13 @@ int vbnmf_matrix_info(const vbnmf_matrix *X, int64_t *n, int64_t *m, int64_t *nn
                       double *sum_lgamma_x1);
 /* The reference's input guards (R/bayesian.R:244-247): counts of all-zero rows / columns. */
 int vbnmf_matrix_empty_counts(const vbnmf_matrix *X, int64_t *empty_rows, int64_t *empty_cols);
+/* Rank classes for a sweep over several ranks on this matrix (the reference's `for(rank in ranks)`, R/bayesian.R:316,
+ * which re-densifies X for every rank and iteration).  The tiled layout depends on the rank only through the LDS row
+ * size; with a plan every engine created afterwards takes the geometry of the smallest class at or above its padded
+ * rank, so the ranks of the sweep share ONE pair of layouts (max_classes = 1: the class of the largest rank) instead of
+ * cutting one per row size.  Results do not depend on the plan beyond the summation order inside a step.
+ * count = 0 clears the plan (every rank its own geometry, the default). */
+int vbnmf_matrix_plan_ranks(vbnmf_matrix *X, const int32_t *ranks, int32_t count, int32_t max_classes);
 void vbnmf_matrix_destroy(vbnmf_matrix *X);
 
 /* ---------------------------------------------------------------------------------
