@@ -1086,7 +1086,7 @@ int vbnmf_layout_build(const vbnmf_matrix *X, int64_t col_begin, int64_t col_end
     vbnmf_layout *H = nullptr;
     try {
         H = new vbnmf_layout();
-        int R = padded_rank(r);
+        int R = std::max(padded_rank(r), plan_class(X, padded_rank(r)));      // the geometry of the rank's class (plan_ranks)
         int64_t nmaj = side == 0 ? X->M.n : col_end - col_begin;
         int64_t nmin = side == 0 ? col_end - col_begin : X->M.n;
         const bool range_ok = col_begin >= 0 && col_end <= X->M.m && col_begin < col_end;      // build_layout reports a bad range

@@ -105,3 +105,29 @@ def test_partition_group_loop_with_many_segments(monkeypatch, r, lds_kb, nwg):
     comm.close()
     for e in parts + [whole]:
         e.close()
+
+
+@pytest.mark.parametrize("r,planned", [(3, (3, 20)), (10, (2, 10, 18)), (12, (12, 40))])
+def test_step_under_a_rank_class_geometry_matches_the_oracle(r, planned):
+    """An engine whose layouts were cut for a LARGER rank of the same sweep (CountMatrix.plan_ranks: wider LDS row stride,
+    narrower blocks) computes the same step: factors 1e-12, evidence 1e-10 against the oracle."""
+    import ccfindr_amd as C
+    from ccfindr_amd import synth
+    from oracle import vbnmf_oracle as O
+    hy = {"aw": 1.0, "bw": 1.0, "ah": 1.0, "bh": 1.0}
+    X = synth.fill_empty(synth.simulate_data(900, [700] * 3, alpha0=0.1, seed=13, depth=np.full(2100, 150)))
+    n, m = X.shape
+    M = C.CountMatrix(X)
+    M.plan_ranks(planned)
+    wh = synth.random_state(n, m, r, hy, seed=r)
+    eng = C.VBEngine(M, r)
+    eng.set_state(wh["lw"], wh["lh"], wh["eh"])
+    lkh, _ = eng.step(hy)
+    got = eng.get_state()
+    eng.close()
+    M.close()
+    want = O.update_csc(n, m, X.indptr, X.indices, X.data, wh, hy, nthreads=8)
+    assert abs(lkh / want["lkh"] - 1) <= 1e-10
+    for k in ("lw", "lh", "ew", "eh", "dw", "dh"):
+        err = float(np.max(np.abs(got[k] - want[k]) / np.abs(want[k])))
+        assert err <= 1e-12, (k, err)

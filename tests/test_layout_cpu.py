@@ -122,3 +122,26 @@ def test_counts_above_the_packed_range_are_split_not_widened():
         assert np.array_equal(A, X if side == 0 else X.T)
     Y = X.copy(); Y[1, 1] = 2.5                       # one non-integer value: the wide layout
     assert build_layout(C.CountMatrix(Y), 0, 6)["wide"]
+
+
+def test_rank_classes_share_one_geometry():
+    """vbnmf_matrix_plan_ranks: every rank of a planned sweep takes the LDS row stride and block width of its class (the
+    largest rank by default), so the layouts -- rank-independent otherwise -- are cut once; the layout still holds X."""
+    import ccfindr_amd as C
+    X = _counts(300, 900, 0.2, seed=21)
+    M = C.CountMatrix(X)
+    own = {r: build_layout(M, 0, r) for r in (3, 10, 20)}
+    assert [own[r]["row_slots"] for r in (3, 10, 20)] == [3, 5, 11]
+    M.plan_ranks([3, 10, 20])
+    for side in (0, 1):
+        views = [build_layout(M, side, r) for r in (3, 10, 20)]
+        for v in views:
+            assert v["row_slots"] == 11 and v["block_width"] * 11 * 16 <= 160 * 1024 - 4112
+        for k in ("packed", "task_major", "slice_width", "slice_off", "inv_task", "seg_ptr", "wg_seg0"):
+            assert all(np.array_equal(views[0][k], v[k]) for v in views[1:]), k
+        assert np.array_equal(reconstruct(views[0]), X if side == 0 else X.T)
+    M.plan_ranks([3, 10, 20], max_classes=2)                 # a second class where the rows are at most half as wide
+    assert [build_layout(M, 0, r)["row_slots"] for r in (3, 10, 20)] == [5, 5, 11]
+    M.plan_ranks(())                                         # cleared: every rank its own geometry again
+    assert build_layout(M, 0, 3)["row_slots"] == 3
+    M.close()
