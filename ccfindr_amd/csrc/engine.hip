@@ -139,6 +139,14 @@ struct vbnmf_engine {
     double seq = 0.0;
     LogTabEntry *logtab = nullptr;    // [128] ln table of the sweep
     LoopCtl *ctl = nullptr;           // control block of the device-driven loop
+    // Unpartitioned VB loop with the control step folded into the gene-side update (kernels.h: ControlFold): two control
+    // blocks and a second table of gene-side block partials, alternating by step; bpW always names the table the latest
+    // queued gene-side update writes (the one every later kernel reads), bpW_alt the other.
+    LoopCtl *ctl2 = nullptr;
+    double *bpW_alt = nullptr;
+    const int32_t *stop_ptr = nullptr;   // the stop flag the kernels of the step being queued read (null: ctl->stop)
+    int fold_step = 0;
+    bool fold = false;
     bool run_active = false;
     unsigned long long *dbg = nullptr;   // diagnostic timestamps of the sweep (VBNMF_DEBUG_TIMES=1)
     size_t dbg_count = 0;
@@ -218,7 +226,7 @@ SweepSide sweep_side_args(const vbnmf_engine *e, const DeviceSide &S, bool gene_
     P.logterm = gene_side ? 1 : 0;
     P.n_wg = S.n_wg;
     P.logtab = e->logtab;
-    P.stop = e->run_active ? &e->ctl->stop : nullptr;
+    P.stop = e->run_active ? (e->stop_ptr ? e->stop_ptr : &e->ctl->stop) : nullptr;
     P.dbg = e->dbg ? e->dbg + (gene_side ? 0 : e->dbg_count / 2) : nullptr;
     return P;
 }
@@ -281,9 +289,13 @@ int launch_sweep(vbnmf_engine *e)
 }
 
 // ctl != nullptr: device-driven loop, the hyper-parameters are read from the control block on the device
-int launch_update(vbnmf_engine *e, bool gene_side, double a, double b, double fudge, const LoopCtl *ctl = nullptr)
+int launch_update(vbnmf_engine *e, bool gene_side, double a, double b, double fudge, const LoopCtl *ctl = nullptr,
+                  const ControlFold *foldp = nullptr)
 {
-    const double lga = ctl ? 0.0 : -std::lgamma(a) + a * std::log(a / b);     // reference :82 / :87
+    ControlFold fold{};
+    if (foldp) fold = *foldp;
+    const unsigned grid = fold.control_only ? 1 : kUpdateBlocks;
+    const double lga = (ctl || foldp) ? 0.0 : -std::lgamma(a) + a * std::log(a / b);     // reference :82 / :87
     const int side = gene_side ? 0 : 1;
     const bool dense = gene_side && e->partitioned;               // statistics already summed into `red`
     const DeviceSide &S = gene_side ? e->A : e->B;
@@ -299,7 +311,7 @@ int launch_update(vbnmf_engine *e, bool gene_side, double a, double b, double fu
     double *ev = gene_side ? e->ew : e->eh, *d = gene_side ? e->dw : e->dh;
     double *bp = gene_side ? e->bpW : e->bpH;
     switch (e->R) {
-#define X(RR) case RR: hipLaunchKernelGGL((k_update<RR>), dim3(kUpdateBlocks), dim3(kUpdateThreads), 0, e->stream, acc, inv_ptr, inv_task, nmaj, e->r, other, other_bp, other_nb, a, b, lga, fudge, l, ll, ev, d, bp, ctl, side); break;
+#define X(RR) case RR: hipLaunchKernelGGL((k_update<RR>), dim3(grid), dim3(kUpdateThreads), 0, e->stream, acc, inv_ptr, inv_task, nmaj, e->r, other, other_bp, other_nb, a, b, lga, fudge, l, ll, ev, d, bp, ctl, side, fold); break;
         VBNMF_FOR_EACH_R(X)
 #undef X
         default: return fail(VBNMF_ERR_BAD_ARG, "unsupported padded rank %d", e->R);
@@ -609,6 +621,7 @@ void vbnmf_engine_destroy(vbnmf_engine *e)
     (void)hipFree(e->red); (void)hipFree(e->red_g); (void)hipFree(e->d_out);
     for (hipEvent_t ev : e->ev_ring) (void)hipEventDestroy(ev);
     if (e->cstream) (void)hipStreamDestroy(e->cstream); (void)hipFree(e->dbg); (void)hipFree(e->logtab); (void)hipFree(e->ctl);
+    (void)hipFree(e->ctl2); (void)hipFree(e->bpW_alt);
     if (e->h_out) (void)hipHostFree(e->h_out);
     if (e->h_hist) (void)hipHostFree(e->h_hist);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
@@ -695,6 +708,12 @@ int vbnmf_engine_create_part(const vbnmf_matrix *X, int64_t cb, int64_t ce, int6
         fill_log_table(tab.data());
         if ((rc = dev_upload(&e->logtab, tab))) return bail(rc);
         if ((rc = dev_alloc(&e->ctl, 1))) return bail(rc);
+        const char *nf = getenv("VBNMF_NO_CONTROL_FOLD");
+        e->fold = !e->partitioned && !(nf && nf[0] == '1');
+        if (e->fold) {
+            if ((rc = dev_alloc(&e->ctl2, 2)) || (rc = dev_alloc(&e->bpW_alt, (size_t)kUpdateBlocks * (e->R + 2)))) return bail(rc);
+            if (hipMemset(e->bpW_alt, 0, (size_t)kUpdateBlocks * (e->R + 2) * sizeof(double)) != hipSuccess) return bail(fail(VBNMF_ERR_HIP, "hipMemset failed"));
+        }
     }
 
     const size_t nR = (size_t)e->n * e->R, mR = (size_t)e->m * e->R;
@@ -991,8 +1010,34 @@ int group_tables(vbnmf_comm *c)
 // so the n*R-double exchange travels while the cell-side sweep runs and only the two-double
 // one sits between the sweep and the control kernel.  The all-reduces are out of place (red -> red_g): steps queued
 // past the stop leave `red` untouched, so repeating them reproduces the same sums.
-int queue_vb_step(const LoopGroup &G, double fudge, bool hist)
+int queue_vb_step(const LoopGroup &G, double fudge, bool hist, int max_it)
 {
+    if (!G.comm && G.e[0]->fold) {
+        // k_update(W, with the control step of the PREVIOUS sweep folded in)  k_update(H)  k_sweep ; behind the last step of
+        // the run, the control step alone (kernels.h: ControlFold)
+        vbnmf_engine *e = G.e[0];
+        const int t = ++e->fold_step;                               // 1-based step of this run
+        ControlFold f{};
+        f.prev = e->ctl2 + ((t - 1) & 1); f.next = e->ctl2 + (t & 1);
+        f.bpW_prev = e->bpW;
+        std::swap(e->bpW, e->bpW_alt);                              // this step's gene-side partials go to the other table
+        f.epart = e->epart; f.nepart = 2 * (int64_t)e->n_wg;
+        f.lgx = e->lgx; f.n = (double)e->n; f.m_global = (double)e->m_global;
+        f.history = hist ? e->h_hist_dev : nullptr; f.out_host = e->h_out_dev;
+        f.do_control = t > 1 ? 1 : 0;
+        int rc = launch_update(e, true, 0, 0, fudge, nullptr, &f);
+        e->stop_ptr = &f.next->stop;
+        if (!rc) rc = launch_update(e, false, 0, 0, fudge, f.next);
+        if (!rc) rc = launch_sweep(e);
+        if (!rc && t == max_it) {
+            ControlFold g = f;
+            g.prev = f.next; g.next = e->ctl2 + ((t + 1) & 1);
+            g.bpW_prev = e->bpW;
+            g.do_control = 1; g.control_only = 1;
+            rc = launch_update(e, true, 0, 0, fudge, nullptr, &g);
+        }
+        return rc;
+    }
     if (!G.comm) {
         vbnmf_engine *e = G.e[0];
         int rc = launch_update(e, true, 0, 0, fudge, e->ctl);
@@ -1122,7 +1167,8 @@ int run_group(const LoopGroup &G, double *hyper, double fudge, int32_t max_it, d
         timing[p] = e->timing;
         e->timing = false;                                         // event pairs cannot follow launches queued ahead
         e->ev_recorded = false; e->ev2_recorded = false;
-        hipLaunchKernelGGL(k_ctl_init, dim3(1), dim3(1), 0, e->stream, e->ctl, c);
+        hipLaunchKernelGGL(k_ctl_init, dim3(1), dim3(1), 0, e->stream, (!G.comm && e->fold) ? e->ctl2 : e->ctl, c);
+        e->fold_step = 0;
         if (G.comm) {                                              // the reduced statistics of the loaded state
             e->red_in = e->red_g;
             (void)hipMemcpyAsync(e->red_g, e->red, (size_t)e->red_count * sizeof(double), hipMemcpyDeviceToDevice, e->stream);
@@ -1146,6 +1192,7 @@ int run_group(const LoopGroup &G, double *hyper, double fudge, int32_t max_it, d
                 e->red_in = nullptr;
             }
             e->run_active = false; e->timing = timing[p];
+            e->stop_ptr = nullptr;
             e->seq = 0.0; e->h_out[7] = 0.0;                       // the step path's sequence flag restarts
         }
         return rc;
@@ -1153,7 +1200,7 @@ int run_group(const LoopGroup &G, double *hyper, double fudge, int32_t max_it, d
     hipError_t he = hipGetLastError();
     if (he != hipSuccess) return cleanup(fail(VBNMF_ERR_HIP, "loading the loop control block failed: %s", hipGetErrorString(he)));
 
-    int rc = drive_loop(e0, max_it, [&]() { return queue_vb_step(G, fudge, history != nullptr); });
+    int rc = drive_loop(e0, max_it, [&]() { return queue_vb_step(G, fudge, history != nullptr, max_it); });
     if (rc) return cleanup(rc);
     for (int p = 0; p < G.count; p++) {
         he = hipStreamSynchronize(G.e[p]->stream);

@@ -574,28 +574,126 @@ struct LoopCtl {
     int32_t flags[4];              // hyper.update
 };
 
+__device__ inline int dev_hyper_update_pair(const int32_t *flags, const double *stats, double *hyper, int lane);
+__device__ __forceinline__ double block_sum(double s, double *sm);
+
+// Device-driven loop of an unpartitioned engine: the control step (k_control below: the evidence of the step just swept,
+// hyper_update, the stopping rule, the history row) FOLDED into the gene-side update of the NEXT step -- one launch
+// and one launch gap less per step (k_control is 8.7 us of latency for a microsecond of work).  Every block of the
+// update forms the control step for itself from the same inputs (the block partials of the two updates and the
+// sweep's evidence partials: identical bits everywhere), so all blocks agree on the new hyper-parameters and on the stop;
+// block 0 alone writes them out.  Nothing a block reads is written in the same launch: the control block and the
+// gene-side block partials alternate between two buffers by step parity (prev / next, bpW_prev / the kernel's bp).
+// After the last step of a run the same kernel is launched once more with control_only = 1 (one block).
+struct ControlFold {
+    const LoopCtl *prev;           // control block as the previous step left it (null: no fold)
+    LoopCtl *next;                 // ... as this launch leaves it (written by block 0)
+    const double *bpW_prev;        // [nb][R+2] block partials of the previous step's gene-side update
+    const double *epart;           // the previous sweep's evidence partials
+    int64_t nepart;
+    double lgx, n, m_global;
+    double *history, *out_host;
+    int32_t do_control;            // 0: first step of a run (nothing to evaluate yet: next = prev)
+    int32_t control_only;          // 1: the launch behind the last step (no update)
+};
+
 template <int R>
 __global__ __launch_bounds__(kUpdateThreads) void k_update(
     const double *__restrict__ acc, const int32_t *__restrict__ inv_ptr, const uint32_t *__restrict__ inv_task,
     int64_t nmaj, int r, const double *__restrict__ other, const double *__restrict__ other_bp, int other_nb,
     double a, double b, double lga, double fudge,
     double *__restrict__ l, double *__restrict__ ll, double *__restrict__ e, double *__restrict__ d, double *__restrict__ bp,
-    const LoopCtl *__restrict__ ctl, int side)
+    const LoopCtl *__restrict__ ctl, int side, const ControlFold fold)
 {
     constexpr int RB = kUpdateThreads / R;       // majors per pass
     __shared__ double s_other[R + 2];
     __shared__ double s_e[kUpdateThreads], s_t[kUpdateThreads], s_l[kUpdateThreads];
     int stopped = 0;
+    const int t = threadIdx.x;
+    if (fold.prev) {
+        // ---- the folded control step (see ControlFold; the arithmetic is k_control's, statement by statement) ----
+        __shared__ double sW[R + 2], s_hy[4];
+        __shared__ int s_stop;
+        const LoopCtl *pv = fold.prev;
+        const int was_stopped = pv->stop;        // (tested below, once the loads of the reductions are in flight too)
+        double part = 0.0;
+        if (fold.do_control) for (int64_t q = t; q < fold.nepart; q += kUpdateThreads) part += fold.epart[q];
+        // column sums of the previous gene-side partials and of the cell-side ones: the latter are also rowSums(eh),
+        // the `other` of this update
+        bp_colsums2(fold.bpW_prev, other_bp, other_nb, R + 2, sW, s_other, kUpdateThreads);
+        if (was_stopped) {                       // a step queued past the stop: the control block and this block's row of the
+            if (blockIdx.x == 0 && t == 0) *fold.next = *pv;                  // gene-side partials travel on unchanged
+            if (t < R + 2 && !fold.control_only) bp[(size_t)blockIdx.x * (R + 2) + t] = fold.bpW_prev[(size_t)blockIdx.x * (R + 2) + t];
+            return;
+        }
+        const double data = block_sum(part, s_e);            // (two barriers: sW, s_other are complete behind it)
+        if (t < 2) {                              // lanes 0 and 1: the two Newton recurrences of hyper_update side by side
+            if (t == 0) for (int q = 0; q < 4; q++) s_hy[q] = pv->hyper[q];
+            int reason = 0, it = pv->it;
+            double lkh = pv->lkh, new_lk0 = pv->lk0;
+            double st[4] = {pv->stats[0], pv->stats[1], pv->stats[2], pv->stats[3]};
+            if (fold.do_control) {
+                double cross = 0.0, sew = 0.0, seh = 0.0;
+                for (int k = 0; k < r; k++) { cross += sW[k] * s_other[k]; sew += sW[k]; seh += s_other[k]; }
+                const double U = -cross - data - fold.lgx + sW[R] + s_other[R];
+                lkh = U / (fold.n * fold.m_global);
+                st[0] = sW[R + 1] / (fold.n * r); st[1] = s_other[R + 1] / (fold.m_global * r);
+                st[2] = sew / (fold.n * r); st[3] = seh / (fold.m_global * r);
+                it = pv->it + 1;
+                if (it > pv->n0 && it % pv->dn == 0) {
+                    if (dev_hyper_update_pair(pv->flags, st, s_hy, t)) reason = 3;
+                }
+                if (t == 0 && !reason) {
+                    const double lk0 = pv->lk0;
+                    if (lkh != lkh) reason = 1;
+                    else if (it > 1 && it > pv->n0 && lkh >= lk0 && fabs(1.0 - lkh / lk0) < pv->tol) reason = 2;
+                    else { new_lk0 = lkh; if (it >= pv->max_it) reason = 4; }
+                }
+            }
+            if (t == 0) {
+                s_stop = reason != 0;
+                if (blockIdx.x == 0) {
+                    LoopCtl nx = *pv;
+                    nx.it = it; nx.lkh = lkh; nx.lk0 = new_lk0;
+                    for (int q = 0; q < 4; q++) { nx.stats[q] = st[q]; nx.hyper[q] = s_hy[q]; }
+                    if (reason) { nx.reason = reason; nx.stop = 1; }
+                    *fold.next = nx;
+                    if (fold.do_control) {
+                        if (fold.history) {
+                            double *h = fold.history + (size_t)(it - 1) * 9;
+                            h[0] = lkh;
+                            for (int q = 0; q < 4; q++) { h[1 + q] = st[q]; h[5 + q] = s_hy[q]; }
+                        }
+                        double *oh = fold.out_host;
+                        oh[0] = lkh;
+                        for (int q = 0; q < 4; q++) { oh[1 + q] = st[q]; oh[8 + q] = s_hy[q]; }
+                        oh[12] = new_lk0;
+                        oh[5] = (double)it;
+                        __threadfence_system();
+                        reinterpret_cast<volatile double *>(oh)[6] = (double)reason;
+                        reinterpret_cast<volatile double *>(oh)[7] = (double)it;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (fold.control_only) return;
+        if (s_stop) {                            // the loop ends here: no update, the partials' row travels on (as above)
+            if (t < R + 2) bp[(size_t)blockIdx.x * (R + 2) + t] = fold.bpW_prev[(size_t)blockIdx.x * (R + 2) + t];
+            return;
+        }
+        a = s_hy[2 * side]; b = s_hy[2 * side + 1];
+    } else {
     if (ctl) {                                   // device-driven loop: hyper-parameters come from the control block
         stopped = ctl->stop;                     // (tested below: these loads and the column sums' travel together)
         a = ctl->hyper[2 * side]; b = ctl->hyper[2 * side + 1];
     }
-    const int t = threadIdx.x;
     if (other_nb > 0) bp_colsums(other_bp, other_nb, R + 2, s_other, kUpdateThreads);
     else if (t < R) s_other[t] = other[t];
     if (stopped) return;
     __syncthreads();
-    if (ctl) {
+    }
+    if (ctl || fold.prev) {
         double psi_a, lg_a;
         dev_psi_lgamma(a, &psi_a, &lg_a);
         lga = -lg_a + a * log(a / b);            // reference src/vbnmf_update.cpp:82 / :87
