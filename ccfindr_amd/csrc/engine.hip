@@ -119,7 +119,8 @@ struct vbnmf_engine {
     double *lw = nullptr, *llw = nullptr, *ew = nullptr, *dw = nullptr;
     double *lh = nullptr, *llh = nullptr, *eh = nullptr, *dh = nullptr;
     double *epart = nullptr;          // [2 * n_wg] evidence partials: gene side, then cell side
-    double *bpW = nullptr, *bpH = nullptr;   // [kUpdateBlocks][R+2] block partials of the two updates
+    double *bpW = nullptr, *bpH = nullptr;   // [ub][R+2] block partials of the two updates (allocated for kUpdateBlocks rows)
+    int ub = kUpdateBlocks;           // blocks of the update kernels (one per CU; VBNMF_UPDATE_BLOCKS for experiments)
     double *red = nullptr;            // [n*R | R+4]  (partitioned engines only use the first part)
     int64_t red_count = 0;
     double *red_g = nullptr;          // same shape: receive side of the all-reduce in a device-driven partitioned loop
@@ -294,7 +295,7 @@ int launch_update(vbnmf_engine *e, bool gene_side, double a, double b, double fu
 {
     ControlFold fold{};
     if (foldp) fold = *foldp;
-    const unsigned grid = fold.control_only ? 1 : kUpdateBlocks;
+    const unsigned grid = fold.control_only ? 1 : e->ub;
     const double lga = (ctl || foldp) ? 0.0 : -std::lgamma(a) + a * std::log(a / b);     // reference :82 / :87
     const int side = gene_side ? 0 : 1;
     const bool dense = gene_side && e->partitioned;               // statistics already summed into `red`
@@ -306,7 +307,7 @@ int launch_update(vbnmf_engine *e, bool gene_side, double a, double b, double fu
     const int64_t nmaj = gene_side ? e->n : e->m;
     const double *other = dense ? redin + (size_t)e->n * e->R : nullptr;
     const double *other_bp = dense ? nullptr : (gene_side ? e->bpH : e->bpW);
-    const int other_nb = dense ? 0 : kUpdateBlocks;
+    const int other_nb = dense ? 0 : e->ub;
     double *l = gene_side ? e->lw : e->lh, *ll = gene_side ? e->llw : e->llh;
     double *ev = gene_side ? e->ew : e->eh, *d = gene_side ? e->dw : e->dh;
     double *bp = gene_side ? e->bpW : e->bpH;
@@ -328,7 +329,7 @@ int launch_prime(vbnmf_engine *e, bool gene_side)
     const double *ev = gene_side ? nullptr : e->eh;
     double *bp = gene_side ? e->bpW : e->bpH;
     switch (e->R) {
-#define X(RR) case RR: hipLaunchKernelGGL((k_prime<RR>), dim3(kUpdateBlocks), dim3(kUpdateThreads), 0, e->stream, nmaj, e->r, l, ll, ev, bp); break;
+#define X(RR) case RR: hipLaunchKernelGGL((k_prime<RR>), dim3(e->ub), dim3(kUpdateThreads), 0, e->stream, nmaj, e->r, l, ll, ev, bp); break;
         VBNMF_FOR_EACH_R(X)
 #undef X
         default: return fail(VBNMF_ERR_BAD_ARG, "unsupported padded rank %d", e->R);
@@ -343,7 +344,7 @@ int launch_final(vbnmf_engine *e)
     const int64_t nep = 2 * (int64_t)e->n_wg;
     e->seq += 1.0;
     switch (e->R) {
-#define X(RR) case RR: hipLaunchKernelGGL((k_final<RR>), dim3(1), dim3(1024), 0, e->stream, e->bpW, kUpdateBlocks, tail, e->bpH, kUpdateBlocks, e->epart, nep, e->lgx, e->r, (double)e->n, (double)e->m_global, e->seq, e->d_out, e->h_out_dev); break;
+#define X(RR) case RR: hipLaunchKernelGGL((k_final<RR>), dim3(1), dim3(1024), 0, e->stream, e->bpW, e->ub, tail, e->bpH, e->ub, e->epart, nep, e->lgx, e->r, (double)e->n, (double)e->m_global, e->seq, e->d_out, e->h_out_dev); break;
         VBNMF_FOR_EACH_R(X)
 #undef X
         default: return fail(VBNMF_ERR_BAD_ARG, "unsupported padded rank %d", e->R);
@@ -358,7 +359,7 @@ int launch_pack(vbnmf_engine *e)
     const int64_t cnt = e->n * e->R;
     hipLaunchKernelGGL(k_pack, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, e->stream, e->A.part, e->A.inv_ptr, e->A.inv_task, e->n, e->R, e->red);
     HIPCHECK(hipGetLastError());
-    hipLaunchKernelGGL(k_tail, dim3(1), dim3(1024), 0, e->stream, e->bpH, kUpdateBlocks, e->R, e->epart,
+    hipLaunchKernelGGL(k_tail, dim3(1), dim3(1024), 0, e->stream, e->bpH, e->ub, e->R, e->epart,
                        2 * (int64_t)e->n_wg, e->lgx, e->red + cnt);
     HIPCHECK(hipGetLastError());
     return VBNMF_OK;
@@ -438,7 +439,7 @@ int launch_ml_update(vbnmf_engine *e, bool gene_side, int prior, double ga, doub
     double *bp = gene_side ? e->bpW : e->bpH;
     const int32_t *stop = e->run_active ? &e->ctl->stop : nullptr;
     switch (e->R) {
-#define X(RR) case RR: hipLaunchKernelGGL((k_ml_update<RR>), dim3(kUpdateBlocks), dim3(kUpdateThreads), 0, e->stream, S.part, S.inv_ptr, S.inv_task, nmaj, e->r, other_bp, kUpdateBlocks, prior, ga, gb, eps, f, bp, stop); break;
+#define X(RR) case RR: hipLaunchKernelGGL((k_ml_update<RR>), dim3(e->ub), dim3(kUpdateThreads), 0, e->stream, S.part, S.inv_ptr, S.inv_task, nmaj, e->r, other_bp, e->ub, prior, ga, gb, eps, f, bp, stop); break;
         VBNMF_FOR_EACH_R(X)
 #undef X
         default: return fail(VBNMF_ERR_BAD_ARG, "unsupported padded rank %d", e->R);
@@ -451,7 +452,7 @@ int launch_ml_final(vbnmf_engine *e)
 {
     e->seq += 1.0;
     switch (e->R) {
-#define X(RR) case RR: hipLaunchKernelGGL((k_ml_final<RR>), dim3(1), dim3(1024), 0, e->stream, e->bpW, e->bpH, kUpdateBlocks, e->epart + e->n_wg, (int64_t)e->n_wg, e->xlx, e->r, (double)e->n, (double)e->m, e->seq, e->d_out, e->h_out_dev); break;
+#define X(RR) case RR: hipLaunchKernelGGL((k_ml_final<RR>), dim3(1), dim3(1024), 0, e->stream, e->bpW, e->bpH, e->ub, e->epart + e->n_wg, (int64_t)e->n_wg, e->xlx, e->r, (double)e->n, (double)e->m, e->seq, e->d_out, e->h_out_dev); break;
         VBNMF_FOR_EACH_R(X)
 #undef X
         default: return fail(VBNMF_ERR_BAD_ARG, "unsupported padded rank %d", e->R);
@@ -656,6 +657,15 @@ int vbnmf_engine_create_part(const vbnmf_matrix *X, int64_t cb, int64_t ce, int6
     e->n = X->M.n; e->m = ce - cb; e->m_global = m_global; e->col_begin = cb;
     e->r = r; e->R = padded_rank(r);
     e->NT = sweep_threads(e->R);
+    {
+        // Blocks of the update kernels.  Fewer than one per CU on small matrices (one pass of the longer factor per block)
+        // was measured and is SLOWER: 200 x 500 at rank 3 36.1 against 30.9 us per step with 2 blocks, 2 000 x 10 000 at
+        // rank 5 82.7 against 79.2 with 59 -- the gather of the task partials is address work (64 scattered 8-byte loads
+        // per wave instruction) that 256 CUs' texture units share and 2 do not.  VBNMF_UPDATE_BLOCKS overrides (experiments).
+        int ub = kUpdateBlocks;
+        if (const char *sv = getenv("VBNMF_UPDATE_BLOCKS")) { int v = atoi(sv); if (v >= 1 && v <= kUpdateBlocks) ub = v; }
+        e->ub = ub;
+    }
     e->wide = !X->M.counts_int;
     e->n_wg = n_cu;                      // one persistent workgroup per CU
     if (const char *sv = getenv("VBNMF_NWG")) { int v = atoi(sv); if (v > 0) e->n_wg = v; }
@@ -958,7 +968,7 @@ int launch_control(vbnmf_engine *e, double *hist_dev, bool reduced)
     const double *tail = reduced ? e->red_g + (size_t)e->n * e->R : nullptr;
     const double *small = reduced ? e->red_g + (size_t)e->n * e->R + e->R + 2 : nullptr;
     switch (e->R) {
-#define X(RR) case RR: hipLaunchKernelGGL((k_control<RR>), dim3(1), dim3(1024), 0, e->stream, e->bpW, e->bpH, kUpdateBlocks, e->epart, nep, e->lgx, e->r, (double)e->n, (double)e->m_global, e->ctl, hist_dev, e->h_out_dev, tail, small); break;
+#define X(RR) case RR: hipLaunchKernelGGL((k_control<RR>), dim3(1), dim3(1024), 0, e->stream, e->bpW, e->bpH, e->ub, e->epart, nep, e->lgx, e->r, (double)e->n, (double)e->m_global, e->ctl, hist_dev, e->h_out_dev, tail, small); break;
         VBNMF_FOR_EACH_R(X)
 #undef X
         default: return fail(VBNMF_ERR_BAD_ARG, "unsupported padded rank %d", e->R);
@@ -1060,7 +1070,7 @@ int queue_vb_step(const LoopGroup &G, double fudge, bool hist, int max_it)
         const int64_t cnt = e->n * e->R;
         hipLaunchKernelGGL(k_pack, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, e->stream, e->A.part, e->A.inv_ptr, e->A.inv_task, e->n, e->R, e->red);
         HIPCHECK(hipGetLastError());
-        hipLaunchKernelGGL(k_tail_h, dim3(1), dim3(1024), 0, e->stream, e->bpH, kUpdateBlocks, e->R, e->red + cnt, &e->ctl->stop);
+        hipLaunchKernelGGL(k_tail_h, dim3(1), dim3(1024), 0, e->stream, e->bpH, e->ub, e->R, e->red + cnt, &e->ctl->stop);
         HIPCHECK(hipGetLastError());
         evA[p] = next_event(e);
         HIPCHECK(hipEventRecord(evA[p], e->stream));
@@ -1479,14 +1489,14 @@ int vbnmf_engine_ml_set_state(vbnmf_engine *e, const double *w, const double *h)
     }
     // colSums(w) block partials, then the cell-side statistics the first H update starts from
     switch (e->R) {
-#define X(RR) case RR: hipLaunchKernelGGL((k_prime<RR>), dim3(kUpdateBlocks), dim3(kUpdateThreads), 0, e->stream, e->n, e->r, e->lw, e->llw, e->lw, e->bpW); break;
+#define X(RR) case RR: hipLaunchKernelGGL((k_prime<RR>), dim3(e->ub), dim3(kUpdateThreads), 0, e->stream, e->n, e->r, e->lw, e->llw, e->lw, e->bpW); break;
         VBNMF_FOR_EACH_R(X)
 #undef X
         default: return fail(VBNMF_ERR_BAD_ARG, "unsupported padded rank %d", e->R);
     }
     HIPCHECK(hipGetLastError());
     switch (e->R) {                                  // rowSums(h) block partials, for the likelihood of the loaded pair
-#define X(RR) case RR: hipLaunchKernelGGL((k_prime<RR>), dim3(kUpdateBlocks), dim3(kUpdateThreads), 0, e->stream, e->m, e->r, e->lh, e->llh, e->lh, e->bpH); break;
+#define X(RR) case RR: hipLaunchKernelGGL((k_prime<RR>), dim3(e->ub), dim3(kUpdateThreads), 0, e->stream, e->m, e->r, e->lh, e->llh, e->lh, e->bpH); break;
         VBNMF_FOR_EACH_R(X)
 #undef X
     }
@@ -1566,7 +1576,7 @@ int vbnmf_engine_ml_run(vbnmf_engine *e, int32_t prior, double gamma_a, double g
         if (!q) q = launch_sweep1(e, false);
         if (q) return q;
         switch (e->R) {
-#define X(RR) case RR: hipLaunchKernelGGL((k_ml_control<RR>), dim3(1), dim3(1024), 0, e->stream, e->bpW, e->bpH, kUpdateBlocks, e->epart + e->n_wg, (int64_t)e->n_wg, e->xlx, e->r, (double)e->n, (double)e->m, e->ctl, hist_dev, e->h_out_dev); break;
+#define X(RR) case RR: hipLaunchKernelGGL((k_ml_control<RR>), dim3(1), dim3(1024), 0, e->stream, e->bpW, e->bpH, e->ub, e->epart + e->n_wg, (int64_t)e->n_wg, e->xlx, e->r, (double)e->n, (double)e->m, e->ctl, hist_dev, e->h_out_dev); break;
             VBNMF_FOR_EACH_R(X)
 #undef X
             default: return fail(VBNMF_ERR_BAD_ARG, "unsupported padded rank %d", e->R);

@@ -5,7 +5,7 @@ HBM bytes per k_sweep launch = 2 x FETCH_SIZE + WRITE_SIZE (both reported in KB;
 the gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md, HBM/rocprofv3 section)."""
 import csv, glob, json, os, sys, collections
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 out = os.path.join("gpurun_out", f"{tag}_summary")
 os.makedirs(out, exist_ok=True)
 
