@@ -14,7 +14,9 @@ repeat bracketed by a barrier + device synchronise; all five times are reported)
     steps queued ahead, the per-step history -- lkh + 4 statistics of EVERY step -- written by the control kernel
     straight into pinned host memory) -> `value`; this is the path ccfindr_amd.vb_factorize runs by default;
   * stepped from the host (vbnmf_engine_step: one call and one read-back of lkh + statistics per iteration, SURVEY.md
-    section 8(d)'s literal metric) -> `host_stepped`.
+    section 8(d)'s literal metric) -> `value_host_stepped` (top level) and the `host_stepped` block.
+`warmup_effective` = W + the settle steps below; `setup` = seconds of untimed set-up (ingestion of X, engine creation =
+the two tiled layouts + their upload, initial state + priming sweep, a second engine on the same matrix).
 The roofline figures of k_sweep come from HIP events around its launches, on the engine's stream, in the host-stepped
 pass (mean per repeat, median over the five repeats, all five in `kernel_ms_repeats`).  `roofline.traffic` is NOT measured in this run: it is the HBM byte count of the rocprofv3 --pmc passes kept
 under profiles/ (`traffic_source` names the file).
@@ -29,7 +31,8 @@ a short K measures the chip at its loaded clocks, not on its way up from idle.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--mode restarts|cells] [--small]
 
-N > 1 (launched by torch.distributed.run, one process per GPU):
+N > 1 (one process per GPU under torch.distributed.run; a BARE `python bench.py --gpus N` starts those ranks itself as a
+child process -- before torch is imported or the GPU touched -- relays rank 0's line and exits with their status):
   --mode restarts (default)  every GPU runs an independent restart of the same factorisation
                              (the reference's own parallelism: mpi.applyLB over runs, reference
                              R/bayesian.R:263); no data-path collective; weak scaling;
