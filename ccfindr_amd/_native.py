@@ -24,7 +24,8 @@ c_int64_p = ctypes.POINTER(ctypes.c_int64)
 c_uint32_p = ctypes.POINTER(ctypes.c_uint32)
 
 OK, ERR_BAD_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_STATE = range(6)
-MAX_RANK = 64
+MAX_RANK = 128
+MAX_SVD_COLUMNS = 64            # vbnmf_engine_svd (device-resident subspace)
 COMM_ID_BYTES = 128
 
 

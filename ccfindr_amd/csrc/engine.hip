@@ -268,9 +268,11 @@ int launch_sweep_r(vbnmf_engine *e, const SweepSide &a, const SweepSide &b)
     return e->wide ? launch_sweep_t<R, true, NT, SP>(e, a, b) : launch_sweep_t<R, false, NT, SP>(e, a, b);
 }
 
-#define VBNMF_FOR_EACH_R(X) \
+#define VBNMF_FOR_EACH_R_UP_TO_64(X) \
     X(2) X(4) X(6) X(8) X(10) X(12) X(14) X(16) X(18) X(20) X(22) X(24) X(26) X(28) X(30) X(32) \
     X(40) X(48) X(56) X(64)
+// every padded rank: up to 32 by 2 (one lane per task), 40..64 by 8 (two lanes), 80..128 by 16 (four lanes)
+#define VBNMF_FOR_EACH_R(X) VBNMF_FOR_EACH_R_UP_TO_64(X) X(80) X(96) X(112) X(128)
 
 int launch_sweep(vbnmf_engine *e)
 {
@@ -1716,7 +1718,7 @@ int launch_gram(vbnmf_engine *e, const double *A, int64_t N)
     SvdWs w = svd_ws(e);
     switch (e->R) {
 #define X(RR) case RR: hipLaunchKernelGGL((k_gram<RR>), dim3(kGramBlocks), dim3(1024), 0, e->stream, A, N, w.gp); break;
-        VBNMF_FOR_EACH_R(X)
+        VBNMF_FOR_EACH_R_UP_TO_64(X)
 #undef X
         default: return fail(VBNMF_ERR_BAD_ARG, "unsupported padded rank %d", e->R);
     }
@@ -1729,7 +1731,7 @@ int launch_small(vbnmf_engine *e, int mode, bool want_s2, double *vals_host, dou
     SvdWs w = svd_ws(e);
     switch (e->R) {
 #define X(RR) case RR: hipLaunchKernelGGL((k_small<RR>), dim3(1), dim3(1024), 0, e->stream, w.gp, kGramBlocks, e->r, mode, w.S, want_s2 ? w.S2 : nullptr, w.vals, vals_host, seq, e->svd_status); break;
-        VBNMF_FOR_EACH_R(X)
+        VBNMF_FOR_EACH_R_UP_TO_64(X)
 #undef X
         default: return fail(VBNMF_ERR_BAD_ARG, "unsupported padded rank %d", e->R);
     }
@@ -1741,7 +1743,7 @@ int launch_apply(vbnmf_engine *e, const double *A, const double *S, int64_t N, d
 {
     switch (e->R) {
 #define X(RR) case RR: hipLaunchKernelGGL((k_apply<RR>), dim3((unsigned)((N + 255) / 256)), dim3(256), 0, e->stream, A, S, N, B); break;
-        VBNMF_FOR_EACH_R(X)
+        VBNMF_FOR_EACH_R_UP_TO_64(X)
 #undef X
         default: return fail(VBNMF_ERR_BAD_ARG, "unsupported padded rank %d", e->R);
     }
@@ -1780,6 +1782,8 @@ int vbnmf_engine_svd(vbnmf_engine *e, int32_t rank_out, double tol, int32_t maxi
     if (!e || !u || !d || !vt) return fail(VBNMF_ERR_BAD_ARG, "NULL argument");
     if (e->partitioned) return fail(VBNMF_ERR_STATE, "the truncated SVD needs an unpartitioned engine");
     if (rank_out < 1 || rank_out > e->r) return fail(VBNMF_ERR_BAD_ARG, "rank_out must be in [1, engine rank]");
+    if (e->R > VBNMF_MAX_SVD_COLUMNS)
+        return fail(VBNMF_ERR_BAD_ARG, "the device-resident SVD holds at most %d subspace columns (engine rank %d); use the sparse products (vbnmf_engine_spmm) with a host QR", VBNMF_MAX_SVD_COLUMNS, e->r);
     if (maxit < 1) return fail(VBNMF_ERR_BAD_ARG, "maxit must be >= 1");
     if (int rc = use_device(e)) return rc;
     e->has_state = false; e->stats_ready = false; e->step_pending = false; e->prime_pending = false; e->ml_ready = false;

@@ -1,7 +1,8 @@
 """Truncated SVD of the count matrix on the MI355X engine: the ``irlba::irlba(mat, rank)`` of the reference's
 ``svd2`` initialiser (R/bayesian.R:150-159) with its two sparse products ``X V`` and ``t(X) U`` run by the sweep
 machinery (``k_spmm``) and, by default, everything else on the device as well (``vbnmf_engine_svd``: the subspace
-never leaves HBM inside the iteration); k = rank + oversampling <= 64 (VBNMF_MAX_RANK).
+never leaves HBM inside the iteration, up to 64 columns; wider subspaces -- ranks above 54 -- take the host-QR form);
+k = rank + oversampling <= 128 (VBNMF_MAX_RANK).
 
 irlba is an implicitly restarted Lanczos bidiagonalisation with ``tol = 1e-5``; this is block subspace iteration with
 the same kind of stopping rule (relative change of the leading singular values) and a tighter default, so the
@@ -31,6 +32,8 @@ def truncated_svd(mat, rank, tol=1e-7, maxit=60, oversample=10, seed=0, device=0
     k = int(min(max(rank + oversample, rank), N.MAX_RANK, n, m))
     if k < rank:
         raise ValueError(f"rank {rank} exceeds the engine's maximum of {N.MAX_RANK}")
+    if k > N.MAX_SVD_COLUMNS:
+        method = "host_qr"                   # the device-resident form holds at most 64 columns; the products still run on the GPU
     eng = VBEngine(M, k, device=device)
     try:
         if method == "device":

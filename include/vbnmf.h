@@ -46,9 +46,11 @@ typedef enum {
 } vbnmf_status;
 
 /* Largest rank an engine takes.  The reference's only bound is rank <= min(n, m) (R/bayesian.R:319-320); here the
- * factor rows live in registers: up to 32 columns per lane, and above that two lanes share a task (ranks 33..64, padded
- * to a multiple of 8). */
-#define VBNMF_MAX_RANK 64
+ * factor rows live in registers: up to 32 columns per lane, above that two lanes share a task (ranks 33..64, padded
+ * to a multiple of 8) and then four (ranks 65..128, padded to a multiple of 16).  The device-resident truncated SVD
+ * (vbnmf_engine_svd) holds subspaces of at most VBNMF_MAX_SVD_COLUMNS columns. */
+#define VBNMF_MAX_RANK 128
+#define VBNMF_MAX_SVD_COLUMNS 64
 
 /* Message of the calling thread's most recent failure ("" if none). Never NULL. */
 const char *vbnmf_last_error(void);

@@ -1,5 +1,6 @@
 """Ranks above 32 (reference limit: rank <= min(n, m) only, R/bayesian.R:319-320): the sweep's lanes share a task's
-columns two by two (padded ranks 40, 48, 56, 64; kernels.h sweep_side SP = 2).  VB step, ML step, resident loop,
+columns two by two (padded ranks 40, 48, 56, 64; kernels.h sweep_side SP = 2) or four by four (ranks 65..128, padded ranks
+80, 96, 112, 128; SP = 4).  VB step, ML step, resident loop,
 sparse product and the partitioned step against the oracles, on every padded rank and both layouts (packed / wide)."""
 import numpy as np
 import pytest
@@ -26,7 +27,7 @@ def counts(n, m, seed, kind="counts"):
 
 
 @pytest.mark.parametrize("kind", ["counts", "noninteger", "binary"])
-@pytest.mark.parametrize("r", [33, 40, 47, 50, 56, 64])
+@pytest.mark.parametrize("r", [33, 40, 47, 50, 56, 64, 65, 80, 90, 100, 112, 128])
 def test_vb_step_above_rank_32(r, kind):
     import ccfindr_amd as C
     from ccfindr_amd import synth
@@ -49,7 +50,7 @@ def test_vb_step_above_rank_32(r, kind):
     eng.close()
 
 
-@pytest.mark.parametrize("r", [36, 64])
+@pytest.mark.parametrize("r", [36, 64, 77, 128])
 def test_stateless_entry_and_margins_above_rank_32(r):
     import ccfindr_amd as C
     from ccfindr_amd import synth
@@ -68,7 +69,7 @@ def test_stateless_entry_and_margins_above_rank_32(r):
     assert np.allclose(alw.sum(axis=1), r * HY["aw"] + X.sum(axis=1), rtol=1e-12)
 
 
-@pytest.mark.parametrize("r", [40, 64])
+@pytest.mark.parametrize("r", [40, 64, 72, 128])
 def test_ml_step_above_rank_32(r):
     import ccfindr_amd as C
     from oracle import mlnmf_oracle as O
@@ -85,14 +86,15 @@ def test_ml_step_above_rank_32(r):
     assert abs(got["lk"] - lk) <= 1e-11 * scale
 
 
-def test_device_loop_above_rank_32_against_the_oracle_steps():
-    """The resident loop (k_control: evidence, hyper-parameter Newton, stop rule) at a shared rank: its history of the
-    first steps against the oracle stepped with the same hyper-parameter updates on the host."""
+@pytest.mark.parametrize("r", [48, 96])
+def test_device_loop_above_rank_32_against_the_oracle_steps(r):
+    """The resident loop (the control step: evidence, hyper-parameter Newton, stop rule) at a shared rank: its history of
+    the first steps against the oracle stepped with the same hyper-parameter updates on the host."""
     import ccfindr_amd as C
     from ccfindr_amd import synth
     from ccfindr_amd.bayesian import hyper_update
     from oracle import vbnmf_oracle as O
-    n, m, r = 140, 300, 48
+    n, m = 140, 300
     hy0 = {"aw": 1.0, "bw": 1.0, "ah": 1.0, "bh": 1.0}
     X = counts(n, m, 11)
     M = C.CountMatrix(X)
@@ -112,10 +114,11 @@ def test_device_loop_above_rank_32_against_the_oracle_steps():
     eng.close()
 
 
-def test_partitions_above_rank_32_equal_whole():
+@pytest.mark.parametrize("r", [40, 80])
+def test_partitions_above_rank_32_equal_whole(r):
     import ccfindr_amd as C
     from ccfindr_amd import synth
-    n, m, r, cut = 100, 210, 40, 90
+    n, m, cut = 100, 210, 90
     X = counts(n, m, 13)
     M = C.CountMatrix(X)
     wh = synth.random_state(n, m, r, HY, seed=3)
@@ -162,3 +165,28 @@ def test_sparse_product_and_truncated_svd_above_rank_32():
         s_ref = np.linalg.svd(X, compute_uv=False)[:36]
         assert np.allclose(s[:8], s_ref[:8], rtol=1e-6), method
         assert np.allclose(U.T @ U, np.eye(U.shape[1]), atol=1e-8), method
+
+
+def test_sparse_product_and_svd_above_64_columns():
+    """Engine ranks above 64 (four lanes per task): the sparse products are there, the device-resident SVD is not (its
+    k x k kernels hold 64 columns: a distinct error), and truncated_svd takes the host-QR form by itself."""
+    import ccfindr_amd as C
+    from ccfindr_amd import linalg
+    n, m, k = 150, 260, 100
+    X = counts(n, m, 23)
+    M = C.CountMatrix(X)
+    rng = np.random.default_rng(1)
+    eng = C.VBEngine(M, k)
+    B = rng.standard_normal((k, m))
+    assert np.allclose(eng.spmm(B, transpose=False), X @ B.T, rtol=1e-12, atol=1e-10)
+    Bt = rng.standard_normal((n, k))
+    assert np.allclose(eng.spmm(Bt, transpose=True), Bt.T @ X, rtol=1e-12, atol=1e-10)
+    with pytest.raises(C.VBNMFError) as ei:
+        eng.svd(5)
+    assert ei.value.code == 1 and "64" in str(ei.value)
+    eng.close()
+    U, s, Vt = linalg.truncated_svd(M, 70)                                # k = 80 columns: host QR over the GPU's products
+    s_ref = np.linalg.svd(X, compute_uv=False)[:70]
+    assert np.allclose(s[:8], s_ref[:8], rtol=1e-6)
+    assert np.allclose(U.T @ U, np.eye(70), atol=1e-8)
+    M.close()
