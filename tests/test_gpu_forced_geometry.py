@@ -107,7 +107,7 @@ def test_partition_group_loop_with_many_segments(monkeypatch, r, lds_kb, nwg):
         e.close()
 
 
-@pytest.mark.parametrize("r,planned", [(3, (3, 20)), (10, (2, 10, 18)), (12, (12, 40))])
+@pytest.mark.parametrize("r,planned", [(3, (3, 20)), (10, (2, 10, 18)), (12, (12, 40)), (40, (40, 100)), (70, (70, 128))])
 def test_step_under_a_rank_class_geometry_matches_the_oracle(r, planned):
     """An engine whose layouts were cut for a LARGER rank of the same sweep (CountMatrix.plan_ranks: wider LDS row stride,
     narrower blocks) computes the same step: factors 1e-12, evidence 1e-10 against the oracle."""
