@@ -224,6 +224,15 @@ SweepSide sweep_side_args(const vbnmf_engine *e, const DeviceSide &S, bool gene_
     P.part = S.part; P.epart = epart;
     P.n_minor = (int32_t)S.n_minor; P.block_start = S.block_start;
     P.row_slots = S.row_slots;
+    {
+        // the youngest third of the workgroup's waves pull slices from the SHORT end of a segment's list (kernels.h:
+        // take_ticket_ends): 768 threads, same box: 2 waves -1.2 us, 4 waves -2.4 us, 6 waves +2 us, 8 waves +7 us on k_sweep
+        // (175.4 us).  VBNMF_PULL_ENDS=k overrides the count (0: everybody pulls longest first, as in rounds 1-2).
+        static const int pe = [] { const char *v = getenv("VBNMF_PULL_ENDS"); return v ? atoi(v) : -1; }();
+        // By rank on the headline matrix (same box, off -> on, k_sweep us): 2: 103.0 -> 103.1, 5: 130.1 -> 132.6, 10: 174.9 ->
+        // 173.2, 16: 308.6 -> 294.1, 20: 391.5 -> 378.3, 32: 865.1 -> 835.5 -- on from padded rank 8.
+        P.pull_ends = pe >= 0 ? std::min(pe, e->NT / 64) : (e->R >= 8 ? (e->NT / 64) / 3 : 0);
+    }
     P.logterm = gene_side ? 1 : 0;
     P.n_wg = S.n_wg;
     P.logtab = e->logtab;

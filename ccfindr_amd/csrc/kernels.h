@@ -60,6 +60,7 @@ struct SweepSide {
     int32_t logterm;               // this side also accumulates sum x*log(wth)
     int32_t n_wg;
     const LogTabEntry *logtab;     // [128] ln table (staged at the front of LDS)
+    int32_t pull_ends;             // the youngest waves pull slices from the short end of a segment's list (take_ticket_ends)
     const int32_t *stop;           // device-driven loop: the sweep returns at once when *stop != 0 (or null)
     unsigned long long *dbg;       // diagnostic: [n_wg][2 + 2*waves] 100 MHz timestamps, or null
 };
@@ -231,6 +232,21 @@ __device__ __forceinline__ int take_ticket(int *ticket)
     return __builtin_amdgcn_readfirstlane(old) >> 6;
 }
 
+// The same list pulled from BOTH ends: the word's low half counts the slices taken from the front (longest first),
+// its high half those taken from the back (shortest first); a pull is valid while front + back < cn and then names
+// front (or cn - 1 - back): every slice exactly once.  The youngest waves of the workgroup pull from the back: the SIMD
+// issues its oldest wave first, so a young wave crawls through whatever it holds -- holding a LONG slice when the
+// tickets run out is what leaves one wave per SIMD running alone at the end of a side (waves 0-3 / 4-7 / 8-11 left the
+// gene side at 77 / 85 / 93 us).  Same construction as above: every lane adds the (wave-uniform) increment.
+__device__ __forceinline__ int take_ticket_ends(int *ticket, int from_back, int cn)
+{
+    const int inc = __builtin_amdgcn_readfirstlane(from_back ? (1 << 16) : 1);
+    const int old = __builtin_amdgcn_readfirstlane(__hip_atomic_fetch_add(ticket, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    const int front = (old & 0xFFFF) >> 6, back = (int)((unsigned)old >> 22);
+    if (front + back >= cn) return cn;
+    return from_back ? cn - 1 - back : front;
+}
+
 // EV selects the per-slice scalar left in the evidence slots: 1 = the VB data term sum(acc . llF) - sum x log(wth)
 // (see the header), 2 = sum x log(wth) alone (ML-NMF likelihood, mlnmf.h), 0 = nothing, 3 = nothing and the entries
 // are accumulated as a plain sparse product (k_spmm).
@@ -252,6 +268,7 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
     if (S.dbg && lane == 0) S.dbg[(size_t)wg * (2 + 2 * (NT / 64)) + 2 + 2 * wave] = __builtin_amdgcn_s_memrealtime();
     if (S.dbg && threadIdx.x == 0) S.dbg[(size_t)wg * (2 + 2 * (NT / 64))] = __builtin_amdgcn_s_memrealtime();
     double ev_wg = 0.0;                                    // this workgroup's evidence, summed in list order (thread 0)
+    const int from_back = wave >= (NT / 64) - S.pull_ends;        // the youngest pull_ends waves (take_ticket_ends)
     double *ev_slot = reinterpret_cast<double *>(reinterpret_cast<char *>(ldsG) + kLdsEvBase);
     int *ticket = reinterpret_cast<int *>(reinterpret_cast<char *>(ldsG) + kLdsCtrBase);
     for (int seg = seg0; seg < seg1; seg++) {
@@ -279,7 +296,7 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
         for (int c0 = l0; c0 < l1; c0 += kLdsEvSlots) {
         const int cn = min(kLdsEvSlots, l1 - c0);
         while (true) {
-            const int i = take_ticket(ticket);
+            const int i = S.pull_ends ? take_ticket_ends(ticket, from_back, cn) : take_ticket(ticket);
             if (i >= cn) break;
             const int s = c0 + i;                          // slices are numbered in processing order
             const int ng = S.slice_width[s] >> 2;
