@@ -244,7 +244,9 @@ __device__ __forceinline__ int take_ticket_ends(int *ticket, int from_back, int 
     const int old = __builtin_amdgcn_readfirstlane(__hip_atomic_fetch_add(ticket, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
     const int front = (old & 0xFFFF) >> 6, back = (int)((unsigned)old >> 22);
     if (front + back >= cn) return cn;
-    return from_back ? cn - 1 - back : front;
+    // (the ticket must be an SGPR for the compiler too: with a lane-valued ticket the slice loop's exit is a divergent
+    // branch and the slice header loads become per-lane -- 150 more wave instructions per slice, measured)
+    return __builtin_amdgcn_readfirstlane(from_back ? cn - 1 - back : front);
 }
 
 // EV selects the per-slice scalar left in the evidence slots: 1 = the VB data term sum(acc . llF) - sum x log(wth)
@@ -268,7 +270,7 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
     if (S.dbg && lane == 0) S.dbg[(size_t)wg * (2 + 2 * (NT / 64)) + 2 + 2 * wave] = __builtin_amdgcn_s_memrealtime();
     if (S.dbg && threadIdx.x == 0) S.dbg[(size_t)wg * (2 + 2 * (NT / 64))] = __builtin_amdgcn_s_memrealtime();
     double ev_wg = 0.0;                                    // this workgroup's evidence, summed in list order (thread 0)
-    const int from_back = wave >= (NT / 64) - S.pull_ends;        // the youngest pull_ends waves (take_ticket_ends)
+    const int from_back = __builtin_amdgcn_readfirstlane((int)(wave >= (NT / 64) - S.pull_ends));   // the youngest waves (take_ticket_ends)
     double *ev_slot = reinterpret_cast<double *>(reinterpret_cast<char *>(ldsG) + kLdsEvBase);
     int *ticket = reinterpret_cast<int *>(reinterpret_cast<char *>(ldsG) + kLdsCtrBase);
     for (int seg = seg0; seg < seg1; seg++) {
@@ -282,9 +284,11 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
             const double2 *G2 = reinterpret_cast<const double2 *>(S.G + (size_t)m0 * RT);
             const int cnt = cw * (RT / 2);
             double2 *rows = ldsG + kLdsRowBase / sizeof(double2);
-            for (int t = threadIdx.x; t < cnt; t += NT) {
-                const int row = t / (RT / 2), kk = t - row * (RT / 2);
-                rows[row * kSlots + kk] = G2[t];
+            if (kSlots == RT / 2) {                        // rows as long as their stride (R / 2 odd, own geometry): a straight copy
+                for (int t = threadIdx.x; t < cnt; t += NT) rows[t] = G2[t];
+            } else {
+                const int pad = kSlots - RT / 2;
+                for (int t = threadIdx.x; t < cnt; t += NT) rows[t + (t / (RT / 2)) * pad] = G2[t];
             }
             if (threadIdx.x < kLogTabSize) ldsG[threadIdx.x] = reinterpret_cast<const double2 *>(S.logtab)[threadIdx.x];
         }
