@@ -512,20 +512,26 @@ __global__ __launch_bounds__(NT) void k_spmm(const SweepSide S)
 }
 
 // Sum of one major's task partials for column k, in the inverse index's fixed order.  The
-// task ids and then the partials are loaded eight at a time so the loads overlap.
+// task ids and then the partials are loaded VBNMF_GATHER_WIDTH at a time so the loads overlap.
+// 16 since round 3 (8 before): 200 x 500 at rank 3 31.2 -> 30.3 us per step, 2 000 x 10 000 at rank 5 78.5 -> 77.7, the
+// headline unchanged (its gather is bound by the sectors it moves, not by round trips); 121 VGPRs, no spill.
+#ifndef VBNMF_GATHER_WIDTH
+#define VBNMF_GATHER_WIDTH 16
+#endif
 __device__ __forceinline__ double task_sum(const double *__restrict__ part, const uint32_t *__restrict__ inv_task,
                                            int q0, int q1, int R, int k)
 {
     double s = 0.0;
-    for (int q = q0; q < q1; q += 8) {
-        uint32_t id[8];
-        double v[8];
+    constexpr int NF = VBNMF_GATHER_WIDTH;
+    for (int q = q0; q < q1; q += NF) {
+        uint32_t id[NF];
+        double v[NF];
 #pragma unroll
-        for (int u = 0; u < 8; u++) id[u] = inv_task[min(q + u, q1 - 1)];
+        for (int u = 0; u < NF; u++) id[u] = inv_task[min(q + u, q1 - 1)];
 #pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = part[(size_t)id[u] * R + k];
+        for (int u = 0; u < NF; u++) v[u] = part[(size_t)id[u] * R + k];
 #pragma unroll
-        for (int u = 0; u < 8; u++) s += (q + u < q1) ? v[u] : 0.0;
+        for (int u = 0; u < NF; u++) s += (q + u < q1) ? v[u] : 0.0;
     }
     return s;
 }
