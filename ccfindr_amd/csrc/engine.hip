@@ -8,8 +8,9 @@
 // raises a sequence flag the host polls (no memcpy, no stream synchronise on the hot path).
 // A cell-partitioned engine adds k_pack + k_tail, which fill the reduce buffer
 // [swsum | rowSum(eh) | scalars] that the caller all-reduces between step_local and step_finish.
-// vbnmf_engine_run drives the whole loop of vb_iterate from the device (k_control after each sweep instead of
-// k_final: hyper_update, stopping rule, per-step history; steps queued ahead of the GPU).
+// vbnmf_engine_run drives the whole loop of vb_iterate from the device (hyper_update, stopping rule, per-step history;
+// steps queued ahead of the GPU): the control step is folded into the next step's gene-side update (kernels.h:
+// ControlFold; three launches per step), partitioned engines run it as the one-block kernel k_control behind each sweep.
 // The same engine also runs the maximum-likelihood NMF step of factorize() (mlnmf.h: two single-side sweeps
 // per step) and the sparse products of the svd2 initialiser's truncated SVD (k_spmm).
 #include <hip/hip_runtime.h>
