@@ -146,6 +146,7 @@ struct vbnmf_engine {
     // queued gene-side update writes (the one every later kernel reads), bpW_alt the other.
     LoopCtl *ctl2 = nullptr;
     double *bpW_alt = nullptr;
+    double *bpH_alt = nullptr;           // the ML loop folds its control step into the H update: the same alternation for bpH
     const int32_t *stop_ptr = nullptr;   // the stop flag the kernels of the step being queued read (null: ctl->stop)
     int fold_step = 0;
     bool fold = false;
@@ -442,16 +443,19 @@ int launch_vb_side(vbnmf_engine *e, bool gene_side)
     return rc;
 }
 
-int launch_ml_update(vbnmf_engine *e, bool gene_side, int prior, double ga, double gb, double eps)
+int launch_ml_update(vbnmf_engine *e, bool gene_side, int prior, double ga, double gb, double eps, const MlFold *foldp = nullptr)
 {
     const DeviceSide &S = gene_side ? e->A : e->B;
     const int64_t nmaj = gene_side ? e->n : e->m;
     const double *other_bp = gene_side ? e->bpH : e->bpW;
     double *f = gene_side ? e->lw : e->lh;
     double *bp = gene_side ? e->bpW : e->bpH;
-    const int32_t *stop = e->run_active ? &e->ctl->stop : nullptr;
+    const int32_t *stop = e->run_active ? (e->stop_ptr ? e->stop_ptr : &e->ctl->stop) : nullptr;
+    MlFold fold{};
+    if (foldp) fold = *foldp;
+    const unsigned grid = fold.control_only ? 1 : (unsigned)e->ub;
     switch (e->R) {
-#define X(RR) case RR: hipLaunchKernelGGL((k_ml_update<RR>), dim3(e->ub), dim3(kUpdateThreads), 0, e->stream, S.part, S.inv_ptr, S.inv_task, nmaj, e->r, other_bp, e->ub, prior, ga, gb, eps, f, bp, stop); break;
+#define X(RR) case RR: hipLaunchKernelGGL((k_ml_update<RR>), dim3(grid), dim3(kUpdateThreads), 0, e->stream, S.part, S.inv_ptr, S.inv_task, nmaj, e->r, other_bp, e->ub, prior, ga, gb, eps, f, bp, stop, fold); break;
         VBNMF_FOR_EACH_R(X)
 #undef X
         default: return fail(VBNMF_ERR_BAD_ARG, "unsupported padded rank %d", e->R);
@@ -634,7 +638,7 @@ void vbnmf_engine_destroy(vbnmf_engine *e)
     (void)hipFree(e->red); (void)hipFree(e->red_g); (void)hipFree(e->d_out);
     for (hipEvent_t ev : e->ev_ring) (void)hipEventDestroy(ev);
     if (e->cstream) (void)hipStreamDestroy(e->cstream); (void)hipFree(e->dbg); (void)hipFree(e->logtab); (void)hipFree(e->ctl);
-    (void)hipFree(e->ctl2); (void)hipFree(e->bpW_alt);
+    (void)hipFree(e->ctl2); (void)hipFree(e->bpW_alt); (void)hipFree(e->bpH_alt);
     if (e->h_out) (void)hipHostFree(e->h_out);
     if (e->h_hist) (void)hipHostFree(e->h_hist);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
@@ -733,8 +737,10 @@ int vbnmf_engine_create_part(const vbnmf_matrix *X, int64_t cb, int64_t ce, int6
         const char *nf = getenv("VBNMF_NO_CONTROL_FOLD");
         e->fold = !e->partitioned && !(nf && nf[0] == '1');
         if (e->fold) {
-            if ((rc = dev_alloc(&e->ctl2, 2)) || (rc = dev_alloc(&e->bpW_alt, (size_t)kUpdateBlocks * (e->R + 2)))) return bail(rc);
-            if (hipMemset(e->bpW_alt, 0, (size_t)kUpdateBlocks * (e->R + 2) * sizeof(double)) != hipSuccess) return bail(fail(VBNMF_ERR_HIP, "hipMemset failed"));
+            if ((rc = dev_alloc(&e->ctl2, 2)) || (rc = dev_alloc(&e->bpW_alt, (size_t)kUpdateBlocks * (e->R + 2))) ||
+                (rc = dev_alloc(&e->bpH_alt, (size_t)kUpdateBlocks * (e->R + 2)))) return bail(rc);
+            if (hipMemset(e->bpW_alt, 0, (size_t)kUpdateBlocks * (e->R + 2) * sizeof(double)) != hipSuccess ||
+                hipMemset(e->bpH_alt, 0, (size_t)kUpdateBlocks * (e->R + 2) * sizeof(double)) != hipSuccess) return bail(fail(VBNMF_ERR_HIP, "hipMemset failed"));
         }
     }
 
@@ -1564,7 +1570,8 @@ int vbnmf_engine_ml_run(vbnmf_engine *e, int32_t prior, double gamma_a, double g
     c.lk0 = -INFINITY;                                             // lkold <- -Inf (:193)
     c.tol = tol; c.max_it = max_it;
     if (history) { if (int rc = ensure_history(e, (size_t)max_it)) return rc; }
-    hipLaunchKernelGGL(k_ctl_init, dim3(1), dim3(1), 0, e->stream, e->ctl, c);
+    hipLaunchKernelGGL(k_ctl_init, dim3(1), dim3(1), 0, e->stream, e->fold ? e->ctl2 : e->ctl, c);
+    e->fold_step = 0;
     hipError_t he = hipGetLastError();
     if (he != hipSuccess) return fail(VBNMF_ERR_HIP, "loading the loop control block failed: %s", hipGetErrorString(he));
     volatile double *ho = e->h_out;
@@ -1577,11 +1584,38 @@ int vbnmf_engine_ml_run(vbnmf_engine *e, int32_t prior, double gamma_a, double g
         if (e->poisoned) return rc;                                 // timed out: the stream may never drain
         (void)hipStreamSynchronize(e->stream);
         e->timing = timing; e->run_active = false;
+        e->stop_ptr = nullptr;
         e->seq = 0.0; e->h_out[7] = 0.0;                            // the step path's sequence flag restarts
         return rc;
     };
     double *hist_dev = history ? e->h_hist_dev : nullptr;
     int rc = drive_loop(e, max_it, [&]() -> int {
+        if (e->fold) {
+            // k_ml_update(H, with the control step of the PREVIOUS cell-side sweep folded in)  sweep  k_ml_update(W)  sweep ;
+            // behind the last step of the run the control step alone (mlnmf.h: MlFold)
+            const int t = ++e->fold_step;
+            MlFold f{};
+            f.prev = e->ctl2 + ((t - 1) & 1); f.next = e->ctl2 + (t & 1);
+            f.bpH_prev = e->bpH;
+            std::swap(e->bpH, e->bpH_alt);                          // this step's H-side partials go to the other table
+            f.epart = e->epart + e->n_wg; f.nepart = (int64_t)e->n_wg;
+            f.xlx = e->xlx; f.n = (double)e->n; f.m = (double)e->m;
+            f.history = hist_dev; f.out_host = e->h_out_dev;
+            f.do_control = t > 1 ? 1 : 0;
+            int q = launch_ml_update(e, false, prior, gamma_a, gamma_b, eps, &f);
+            e->stop_ptr = &f.next->stop;
+            if (!q) q = launch_sweep1(e, true);
+            if (!q) q = launch_ml_update(e, true, prior, gamma_a, gamma_b, eps);
+            if (!q) q = launch_sweep1(e, false);
+            if (!q && t == max_it) {
+                MlFold g = f;
+                g.prev = f.next; g.next = e->ctl2 + ((t + 1) & 1);
+                g.bpH_prev = e->bpH;
+                g.do_control = 1; g.control_only = 1;
+                q = launch_ml_update(e, false, prior, gamma_a, gamma_b, eps, &g);
+            }
+            return q;
+        }
         int q = launch_ml_update(e, false, prior, gamma_a, gamma_b, eps);
         if (!q) q = launch_sweep1(e, true);
         if (!q) q = launch_ml_update(e, true, prior, gamma_a, gamma_b, eps);

@@ -19,20 +19,88 @@ namespace vbnmf {
 //   s    = sum of the major's task partials (fixed order)          = (t(w) %*% (x/wh))[k, major] or its W twin
 //   up   = f * s [+ a - 1] ; down = colsum_other[k] [+ a/b] ; f <- max(up / down, eps)   (NaN stays NaN, as in R)
 // other_bp[other_nb][R+2] are the OTHER factor's block partials of its column sums; this factor's go to bp.
+// The control step of the device-driven ML loop (k_ml_control below) folded into the H update of the NEXT step, exactly as
+// the VB loop folds its own into the gene-side update (kernels.h: ControlFold): every block forms it from the same
+// inputs, block 0 writes it out, and what a block reads is never written in the same launch (the control block and the
+// table of H-side block partials alternate between two buffers by step parity).
+struct MlFold {
+    const LoopCtl *prev;           // null: no fold
+    LoopCtl *next;
+    const double *bpH_prev;        // [nb][R+2] block partials of the previous step's H update
+    const double *epart;           // the previous cell-side sweep's sum x log(wh) partials
+    int64_t nepart;
+    double xlx, n, m;
+    double *history, *out_host;
+    int32_t do_control, control_only;
+};
+
 template <int R>
 __global__ __launch_bounds__(kUpdateThreads) void k_ml_update(
     const double *__restrict__ part, const int32_t *__restrict__ inv_ptr, const uint32_t *__restrict__ inv_task,
     int64_t nmaj, int r, const double *__restrict__ other_bp, int other_nb, int prior, double ga, double gb, double eps,
-    double *__restrict__ f, double *__restrict__ bp, const int32_t *__restrict__ stop)
+    double *__restrict__ f, double *__restrict__ bp, const int32_t *__restrict__ stop, const MlFold fold)
 {
     constexpr int RB = kUpdateThreads / R;       // majors per pass
     __shared__ double s_other[R + 2];
     __shared__ double s_e[kUpdateThreads];
-    const int stopped = stop ? *stop : 0;        // device-driven loop: the run has ended, leave the factors as they are
     const int t = threadIdx.x;
+    if (fold.prev) {
+        // ---- the folded control step: k_ml_control's arithmetic, statement by statement ----
+        __shared__ double sH[R + 2];
+        __shared__ int s_stop;
+        const LoopCtl *pv = fold.prev;
+        const int was_stopped = pv->stop;
+        double pe = 0.0;
+        if (fold.do_control) for (int64_t q = t; q < fold.nepart; q += kUpdateThreads) pe += fold.epart[q];
+        bp_colsums2(other_bp, fold.bpH_prev, other_nb, R + 2, s_other, sH, kUpdateThreads);   // colSums(w) (this update's `down`), colSums(h)
+        if (was_stopped) {                       // a step queued past the stop: everything travels on unchanged
+            if (blockIdx.x == 0 && t == 0) *fold.next = *pv;
+            if (t < R + 2 && !fold.control_only) bp[(size_t)blockIdx.x * (R + 2) + t] = fold.bpH_prev[(size_t)blockIdx.x * (R + 2) + t];
+            return;
+        }
+        const double data = block_sum(pe, s_e);
+        if (t == 0) {
+            int reason = 0, it = pv->it;
+            double lk = pv->lkh, new_lk0 = pv->lk0;
+            if (fold.do_control) {
+                double cross = 0.0;
+                for (int k = 0; k < r; k++) cross += s_other[k] * sH[k];
+                lk = ((data - cross) + fold.xlx) / fold.n / fold.m;
+                it = pv->it + 1;
+                const double lkold = pv->lk0;
+                if (fabs(lkold - lk) < pv->tol * fabs(lkold)) reason = 2;           // converged (R/factorize.R:211)
+                else { new_lk0 = lk; if (it >= pv->max_it) reason = 4; }
+            }
+            s_stop = reason != 0;
+            if (blockIdx.x == 0) {
+                LoopCtl nx = *pv;
+                nx.it = it; nx.lkh = lk; nx.lk0 = new_lk0;
+                if (reason) { nx.reason = reason; nx.stop = 1; }
+                *fold.next = nx;
+                if (fold.do_control) {
+                    if (fold.history) fold.history[it - 1] = lk;
+                    double *oh = fold.out_host;
+                    oh[0] = lk;
+                    oh[12] = new_lk0;
+                    oh[5] = (double)it;
+                    __threadfence_system();
+                    reinterpret_cast<volatile double *>(oh)[6] = (double)reason;
+                    reinterpret_cast<volatile double *>(oh)[7] = (double)it;
+                }
+            }
+        }
+        __syncthreads();
+        if (fold.control_only) return;
+        if (s_stop) {
+            if (t < R + 2) bp[(size_t)blockIdx.x * (R + 2) + t] = fold.bpH_prev[(size_t)blockIdx.x * (R + 2) + t];
+            return;
+        }
+    } else {
+    const int stopped = stop ? *stop : 0;        // device-driven loop: the run has ended, leave the factors as they are
     bp_colsums(other_bp, other_nb, R + 2, s_other, kUpdateThreads);       // (its loads travel with the flag's)
     if (stopped) return;
     __syncthreads();
+    }
 
     const int row = t / R, k = t - row * R;
     const int64_t per = (nmaj + gridDim.x - 1) / gridDim.x;

@@ -106,3 +106,34 @@ def test_fold_nan_evidence_breaks_with_reason_1(problem):
     assert outs[0]["reason"] == outs[1]["reason"] and outs[0]["it"] == outs[1]["it"]
     assert outs[0]["reason"] in (1, 4)
     assert np.array_equal(np.isnan(outs[0]["history"][:, 0]), np.isnan(outs[1]["history"][:, 0]))
+
+
+@pytest.mark.parametrize("Itmax,Tol,prior", [(1, 0.0, False), (2, 0.0, False), (9, 0.0, True), (16, 0.0, False), (17, 0.0, False),
+                                             (400, 1e-4, False), (400, 3e-4, True)])
+def test_ml_loop_fold_and_separate_control_agree_bit_for_bit(problem, Itmax, Tol, prior):
+    """The same for the maximum-likelihood loop of factorize() (mlnmf.h: MlFold into the H update; reference
+    R/factorize.R:194-213): iteration count, stop reason, likelihood history and the factors, then a second run and a
+    host-stepped step from the state the first one left."""
+    M, n, m = problem
+    r = 4
+    rng = np.random.default_rng(12)
+    w0, h0 = rng.uniform(0.1, 1.0, size=(n, r)), rng.uniform(0.1, 1.0, size=(r, m))
+    outs = []
+    for fold in (True, False):
+        eng = _engine(M, r, {"lw": w0, "lh": h0, "eh": h0}, fold)
+        eng.ml_set_state(w0, h0)
+        a = eng.ml_run(Itmax=Itmax, Tol=Tol, prior=prior, gamma_a=1.3, gamma_b=0.8, history=True)
+        b = eng.ml_run(Itmax=5, Tol=0.0, prior=prior, gamma_a=1.3, gamma_b=0.8, history=True)
+        lk = eng.ml_step(prior=prior, gamma_a=1.3, gamma_b=0.8)
+        st = eng.ml_get_state()
+        eng.close()
+        outs.append((a, b, lk, st["ew"], st["eh"]))
+    for x, y in ((outs[0][0], outs[1][0]), (outs[0][1], outs[1][1])):
+        assert x["it"] == y["it"] and x["reason"] == y["reason"] and x["lk"] == y["lk"]
+        assert np.array_equal(x["history"], y["history"])
+    if Tol > 0:
+        assert outs[0][0]["reason"] == 2 and outs[0][0]["it"] < 400
+    else:
+        assert outs[0][0]["it"] == Itmax and outs[0][0]["reason"] == 4
+    assert outs[0][2] == outs[1][2]
+    assert np.array_equal(outs[0][3], outs[1][3]) and np.array_equal(outs[0][4], outs[1][4])
