@@ -227,13 +227,21 @@ SweepSide sweep_side_args(const vbnmf_engine *e, const DeviceSide &S, bool gene_
     P.n_minor = (int32_t)S.n_minor; P.block_start = S.block_start;
     P.row_slots = S.row_slots;
     {
-        // the youngest third of the workgroup's waves pull slices from the SHORT end of a segment's list (kernels.h:
-        // take_ticket_ends): 768 threads, same box: 2 waves -1.2 us, 4 waves -2.4 us, 6 waves +2 us, 8 waves +7 us on k_sweep
-        // (175.4 us).  VBNMF_PULL_ENDS=k overrides the count (0: everybody pulls longest first, as in rounds 1-2).
+        // The youngest third of the workgroup's waves pull slices from the SHORT end of a segment's list (kernels.h:
+        // take_ticket_ends).  Measured per side, interleaved, on two boxes (k_sweep us, rank 10, 768 threads: neither side /
+        // gene side only / cell side only / both): 171.5 / 170.0 / 175.5 / 172.5 and 168.7 / 166.7 / 171.9 / 169.9 -- the gene
+        // side gains, the cell side (no logarithm, shorter slices) loses at this geometry; at the 512-thread ranks both
+        // sides gain (neither / gene / both: rank 16 294.1 / 285.7 / 284.8, rank 20 378.9 / 369.0 / 365.3, rank 32 859 / 845 /
+        // 838); below padded rank 8 it loses on both (rank 5: 121.1 / 127.3 / 129.3).  So: the gene side from padded rank
+        // 8, the cell side from 16.  VBNMF_PULL_ENDS=k overrides the count on both sides, VBNMF_PULL_ENDS_A / _B per side.
         static const int pe = [] { const char *v = getenv("VBNMF_PULL_ENDS"); return v ? atoi(v) : -1; }();
-        // By rank on the headline matrix (same box, off -> on, k_sweep us): 2: 103.0 -> 103.1, 5: 130.1 -> 132.6, 10: 174.9 ->
-        // 173.2, 16: 308.6 -> 294.1, 20: 391.5 -> 378.3, 32: 865.1 -> 835.5 -- on from padded rank 8.
-        P.pull_ends = pe >= 0 ? std::min(pe, e->NT / 64) : (e->R >= 8 ? (e->NT / 64) / 3 : 0);
+        static const int pes[2] = {[] { const char *v = getenv("VBNMF_PULL_ENDS_A"); return v ? atoi(v) : -1; }(),
+                                   [] { const char *v = getenv("VBNMF_PULL_ENDS_B"); return v ? atoi(v) : -1; }()};
+        const int third = (e->NT / 64) / 3;
+        int k = gene_side ? (e->R >= 8 ? third : 0) : (e->R >= 16 ? third : 0);
+        if (pe >= 0) k = pe;
+        if (pes[gene_side ? 0 : 1] >= 0) k = pes[gene_side ? 0 : 1];
+        P.pull_ends = std::min(k, e->NT / 64);
     }
     P.logterm = gene_side ? 1 : 0;
     P.n_wg = S.n_wg;
