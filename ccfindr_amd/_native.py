@@ -48,6 +48,7 @@ class LayoutView(ctypes.Structure):
         ("block_start", c_int64_p), ("seg_block", c_int32_p), ("wg_seg0", c_int32_p), ("seg_ptr", c_int32_p),
         ("inv_ptr", c_int32_p), ("inv_task", c_uint32_p),
         ("packed", c_uint32_p), ("wide_idx", c_uint32_p), ("wide_val", c_double_p),
+        ("cell_perm", c_int32_p),
     ]
 
 
@@ -67,9 +68,18 @@ SIGNATURES = {
     "vbnmf_matrix_info": (ctypes.c_int, [_VP, c_int64_p, c_int64_p, c_int64_p, c_double_p]),
     "vbnmf_matrix_empty_counts": (ctypes.c_int, [_VP, c_int64_p, c_int64_p]),
     "vbnmf_matrix_plan_ranks": (ctypes.c_int, [_VP, c_int32_p, _I32, _I32]),
+    "vbnmf_plan_classes": (ctypes.c_int, [c_int32_p, _I32, _I32, c_int32_p, c_int32_p]),
+    "vbnmf_padded_rank": (_I32, [_I32]),
+    "vbnmf_matrix_get_meta": (ctypes.c_int, [_VP, c_double_p]),
+    "vbnmf_matrix_shell": (ctypes.c_int, [c_double_p, _VPP]),
+    "vbnmf_matrix_is_shell": (ctypes.c_int, [_VP]),
+    "vbnmf_matrix_export_layout": (ctypes.c_int, [_VP, _I32, _I32, _I32, _VP, _I64, c_int64_p]),
+    "vbnmf_matrix_import_layout": (ctypes.c_int, [_VP, _VP, _I64]),
+    "vbnmf_device_sweep_workgroups": (ctypes.c_int, [_I32, c_int32_p]),
     "vbnmf_matrix_destroy": (None, [_VP]),
     "vbnmf_engine_create": (ctypes.c_int, [_VP, _I32, _I32, _VPP]),
     "vbnmf_engine_create_part": (ctypes.c_int, [_VP, _I64, _I64, _I64, _I32, _I32, _VPP]),
+    "vbnmf_engine_create_geom": (ctypes.c_int, [_VP, _I64, _I64, _I64, _I32, _I32, _I32, _VPP]),
     "vbnmf_engine_destroy": (None, [_VP]),
     "vbnmf_engine_dims": (ctypes.c_int, [_VP, c_int64_p, c_int64_p, c_int32_p]),
     "vbnmf_engine_set_state": (ctypes.c_int, [_VP, c_double_p, c_double_p, c_double_p]),
@@ -121,6 +131,7 @@ SIGNATURES = {
     "vbnmf_test_special_host": (ctypes.c_int, [_I32, _I64, c_double_p, c_double_p]),
     "vbnmf_test_special_device": (ctypes.c_int, [_I32, _I64, c_double_p, c_double_p]),
     "vbnmf_test_stream_sleep": (ctypes.c_int, [_VP, _D]),
+    "vbnmf_test_hash_bytes": (ctypes.c_uint64, [_VP, _I64, ctypes.c_uint64]),
 }
 
 _lib = None

@@ -24,7 +24,7 @@ from dataclasses import dataclass, field
 import numpy as np
 
 from . import _native as N
-from .engine import EPS, CountMatrix, VBEngine
+from .engine import EPS, CountMatrix, VBEngine, geometry_rank_for, rank_classes
 
 import ctypes
 
@@ -257,7 +257,8 @@ def _make_engine(bundle, rank):
     if cache is not None and key in cache:
         return cache[key]
     factory = bundle.get("engine_factory")
-    eng = factory(bundle["mat"], rank) if factory is not None else VBEngine(bundle["mat"], rank, device=bundle.get("device", 0))
+    eng = (factory(bundle["mat"], rank) if factory is not None else
+           VBEngine(bundle["mat"], rank, device=bundle.get("device", 0), geometry_rank=geometry_rank_for(rank, bundle.get("classes"))))
     if cache is not None:
         cache[key] = eng
     return eng
@@ -283,15 +284,21 @@ def vb_run_rank(irun, rank, bundle):
     hyper = {"aw": float(ga[0]), "ah": float(ga[-1]), "bw": float(gb[0]), "bh": float(gb[-1])}   # :321-326
     rng = _bundle_rng(bundle, irun, rank)
     raw = bundle.get("raw")
+    clock = bundle.get("unit_times")                     # optional: seconds per phase of this unit (drivers' diagnostics)
+    import time
+    t_0 = time.perf_counter()
     eng = _make_engine(bundle, rank)
+    t_eng = time.perf_counter()
     on_device = bundle.get("device_init") and bundle["initializer"] == "random" and hasattr(eng, "random_state")
     wh0 = None if on_device else vb_init(nrow, ncol, raw if raw is not None else X, rank, hyper=hyper,
                                          initializer=bundle["initializer"], rng=rng, device=bundle.get("device", 0))
+    t_draw = time.perf_counter()
     try:
         if on_device:
             eng.random_state(hyper, int(rng.integers(1 << 63)))                  # :111-115 on the GPU
         else:
             eng.set_state(wh0["lw"], wh0["lh"], wh0["eh"])
+        t_state = time.perf_counter()
         lk0 = 0.0
         it = 0
         device_loop = bundle.get("device_loop", True) and verbose < 3 and hasattr(eng, "run")
@@ -313,7 +320,21 @@ def vb_run_rank(irun, rank, bundle):
             if verbose >= 3:
                 print(f"{it}, log(evidence) = {lk0}, aw = {hyper['aw']}, bw = {hyper['bw']}, "
                       f"ah = {hyper['ah']}, bh = {hyper['bh']}")
-        wh = eng.get_state(("ew", "eh", "dw", "dh"))
+        # the unit's factor matrices: into caller-provided storage when the driver has some (a sharded sweep collects them
+        # in memory shared by the node's processes, ccfindr_amd.parallel), else fresh arrays
+        t_loop = time.perf_counter()
+        slots = bundle["state_out"](irun, rank) if bundle.get("state_out") is not None else None
+        if slots is not None and getattr(eng, "supports_state_out", False):
+            wh = eng.get_state(("ew", "eh", "dw", "dh"), out=slots)
+        else:
+            wh = eng.get_state(("ew", "eh", "dw", "dh"))
+            if slots is not None:
+                for key in ("ew", "eh", "dw", "dh"):
+                    slots[key][...] = wh[key]
+                wh = slots
+        if clock is not None:
+            clock.append({"rank": rank, "engine_s": t_eng - t_0, "draw_s": t_draw - t_eng, "set_state_s": t_state - t_draw,
+                          "loop_s": t_loop - t_state, "get_state_s": time.perf_counter() - t_loop, "it": it})
     finally:
         if bundle.get("engines") is None:
             eng.close()
@@ -322,7 +343,12 @@ def vb_run_rank(irun, rank, bundle):
               f"{hyper['ah']},{hyper['bh']})")
     ew = wh["ew"]
     contains_unif = np.abs(ew.max(axis=0) - ew.min(axis=0)) < bundle["Tol"]      # :368-369
-    return {"rank": rank, "lk0": lk0, "ew": wh["ew"], "eh": wh["eh"], "sdw": np.sqrt(wh["dw"]), "sdh": np.sqrt(wh["dh"]),  # :382-383
+    if slots is not None:                                                        # sqrt in place: the storage is the record
+        np.sqrt(wh["dw"], out=wh["dw"]); np.sqrt(wh["dh"], out=wh["dh"])
+        sdw, sdh = wh["dw"], wh["dh"]
+    else:
+        sdw, sdh = np.sqrt(wh["dw"]), np.sqrt(wh["dh"])
+    return {"rank": rank, "lk0": lk0, "ew": wh["ew"], "eh": wh["eh"], "sdw": sdw, "sdh": sdh,  # :382-383
             "hyper": hyper, "nsteps": it, "unif": [int(c) + 1 for c in np.nonzero(contains_unif)[0]]}
 
 
@@ -396,7 +422,9 @@ def make_bundle(mat, ranks, nrun, verbose, initializer, Itmax, hyper_update, gam
     if initializer in ("svd", "svd2") and nrun > 1:
         raise ValueError("SVD initializer does not require nrun > 1")            # :241-242
     X = mat if isinstance(mat, CountMatrix) else CountMatrix(mat)
-    nullr, nullc = X.empty_counts()                                              # :244-245
+    # (a shell -- CountMatrix.shell, a sharded sweep's processes that do not hold X -- has no entries to check: the
+    # process that holds them ran these guards and every process raises on its findings, ccfindr_amd.parallel)
+    nullr, nullc = (0, 0) if getattr(X, "is_shell", False) else X.empty_counts()   # :244-245
     if nullr > 0:
         raise ValueError("Input matrix contains empty rows")
     if nullc > 0:
@@ -410,17 +438,18 @@ def make_bundle(mat, ranks, nrun, verbose, initializer, Itmax, hyper_update, gam
 
 
 def plan_geometry(bundle, geometry_classes=1):
-    """A sweep over several ranks shares ONE pair of tiled layouts (``CountMatrix.plan_ranks``): the geometry of the
-    largest rank (``geometry_classes`` = 1), or up to that many classes.  Cutting a pair per LDS row size cost the
-    reference-default sweep of BASELINE config C4 (ranks 2..20) 5 s of host time against 0.3 s of stepping; the price is
-    a somewhat slower step at the lower ranks (narrower LDS blocks than their rows would allow).  0 = every rank its own
-    geometry.  Returns True when a plan was set (the caller clears it afterwards)."""
-    X = bundle["mat"]
+    """A sweep over several ranks shares ONE pair of tiled layouts: the geometry of the largest rank
+    (``geometry_classes`` = 1), or up to that many classes (``ccfindr_amd.engine.rank_classes``).  Cutting a pair per LDS
+    row size cost the reference-default sweep of BASELINE config C4 (ranks 2..20) 5 s of host time against 0.3 s of
+    stepping; the price is a somewhat slower step at the lower ranks (narrower LDS blocks than their rows would allow).
+    0 = every rank its own geometry.  The classes go into ``bundle["classes"]`` and from there to each engine
+    (``VBEngine(geometry_rank=...)``): the matrix handle is not touched, so a plan the caller set with
+    ``CountMatrix.plan_ranks`` survives and concurrent sweeps on one matrix do not disturb each other."""
     ranks = sorted({int(r) for r in bundle["ranks"]})
-    if geometry_classes and len(ranks) > 1 and hasattr(X, "plan_ranks"):
-        X.plan_ranks(ranks, geometry_classes)
-        return True
-    return False
+    bundle["classes"] = []
+    if geometry_classes and len(ranks) > 1 and bundle.get("engine_factory") is None:
+        bundle["classes"] = rank_classes(ranks, geometry_classes)
+    return bundle["classes"]
 
 
 def vb_factorize(mat, ranks=2, nrun=1, verbose=2, progress_bar=True, initializer="random", Itmax=10000,
@@ -446,6 +475,10 @@ def vb_factorize(mat, ranks=2, nrun=1, verbose=2, progress_bar=True, initializer
     Marsaglia-Tsang, one key per (seed, run, rank)) instead of with numpy on the host; off by default so that runs
     with an injected engine and runs on the HIP engine start from the same arrays.
     ``geometry_classes``: see ``plan_geometry`` (several ranks share the tiled layouts of the largest one; 0 = off).
+    With shared layouts a rank's numbers depend, in the last bits, on WHICH ranks are in the sweep: the geometry fixes the
+    order in which a step's partial sums are added (every result stays inside the 1e-12 / 1e-10 tolerances of one step,
+    and any given sweep is bit-reproducible).  To re-run one rank of a sweep and get the same bits, pass the same
+    ``ranks`` list again or use ``geometry_classes=0`` (every rank in its own geometry) for both runs.
     """
     del progress_bar, useC, ncores
     if connectivity:
@@ -456,7 +489,7 @@ def vb_factorize(mat, ranks=2, nrun=1, verbose=2, progress_bar=True, initializer
     bundle["device_init"] = bool(device_init)
     bundle["concurrent"] = max(1, int(concurrent))
     bundle["engines"] = {} if (nrun > 1 or bundle["concurrent"] > 1) else None   # restarts of a rank reuse its engine
-    planned = plan_geometry(bundle, geometry_classes)
+    plan_geometry(bundle, geometry_classes)
     try:
         if bundle["concurrent"] > 1:
             from concurrent.futures import ThreadPoolExecutor
@@ -471,6 +504,4 @@ def vb_factorize(mat, ranks=2, nrun=1, verbose=2, progress_bar=True, initializer
             vb = [vb_iterate(irun, bundle) for irun in range(1, nrun + 1)]       # :260-261
     finally:
         _close_engines(bundle)
-        if planned:
-            bundle["mat"].plan_ranks(())
     return select_best(vb, bundle["ranks"])

@@ -7,7 +7,8 @@
 //   * RCCL (one process per GPU, xGMI): ncclAllReduce(sum, fp64) enqueued from C++ on a stream of the engine, so the
 //     device-driven loop needs no host round trip and no Python between steps.  librccl is opened at run time
 //     (dlopen "librccl.so.1"): the library still loads on a box without RCCL, and in a process that already carries
-//     a copy (PyTorch ships one under the same SONAME) that copy is the one used.
+//     a copy (PyTorch ships one under the same SONAME) that copy is the one used.  VBNMF_RCCL_LIB names another
+//     library exporting the same eight symbols (test infrastructure only: tests/fake_rccl).
 //   * local group: the partition engines live in ONE process on ONE device (tests, single-GPU rehearsals of a
 //     partitioned run: RCCL refuses two ranks on a device); the sum is a kernel (k_group_sum) in partition order.
 #pragma once
@@ -42,12 +43,19 @@ inline RcclApi &rccl_api()
     static RcclApi api;
     static std::once_flag once;
     std::call_once(once, [] {
+        // VBNMF_RCCL_LIB=<path> names the library to open instead (tests/fake_rccl: a stand-in that accepts several ranks
+        // on one device, so the multi-rank protocol can be rehearsed on a one-GPU box); it must open, there is no second try.
+        const char *forced = getenv("VBNMF_RCCL_LIB");
         const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-        for (const char *nm : names) {
-            api.handle = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
-            if (api.handle) break;
+        if (forced && *forced) {
+            api.handle = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+        } else {
+            for (const char *nm : names) {
+                api.handle = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+                if (api.handle) break;
+            }
         }
-        if (!api.handle) { api.error = std::string("librccl could not be opened: ") + (dlerror() ? dlerror() : "?"); return; }
+        if (!api.handle) { api.error = std::string(forced && *forced ? "VBNMF_RCCL_LIB could not be opened: " : "librccl could not be opened: ") + (dlerror() ? dlerror() : "?"); return; }
         auto sym = [&](const char *nm) { void *p = dlsym(api.handle, nm); if (!p && api.error.empty()) api.error = std::string("librccl lacks ") + nm; return p; };
         api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
         api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));

@@ -34,6 +34,12 @@ struct RowMajorCache {
     std::once_flag once;
     RowMajor rm;
 };
+// The layout-internal renumbering of the cells of the WHOLE matrix (order.cpp): perm[p] = the original column stored
+// at position p; empty = identity.  Computed once per matrix (a shell takes it from the first imported layout).
+struct CellOrderCache {
+    std::once_flag once;
+    std::vector<int32_t> perm;
+};
 
 // ---- canonical host copy of X: CSC, rows ascending in each column, no zeros, no dups ----
 struct Matrix {
@@ -42,7 +48,11 @@ struct Matrix {
     std::vector<int32_t> row;      // nnz
     std::vector<double> val;       // nnz
     std::shared_ptr<RowMajorCache> rm_cache = std::make_shared<RowMajorCache>();
-    const RowMajor &row_major() const;   // lazily built, thread-safe; engines of every rank on this matrix share it
+    const RowMajor &row_major() const;   // lazily built, thread-safe; engines of every rank on this matrix share it.
+                                         // Column ids are POSITIONS in cell_order() (the gene side's minors).
+    std::shared_ptr<CellOrderCache> order_cache = std::make_shared<CellOrderCache>();
+    const std::vector<int32_t> &cell_order() const;   // whole matrix; lazily computed, thread-safe
+    bool shell = false;            // metadata only (vbnmf_matrix_shell): no entries; layouts come from vbnmf_matrix_import_layout
     bool counts_u16 = false;       // every stored value is an integer in [1, kPackedCountMax]
     bool counts_int = false;       // every stored value is an integer in [1, 2^31): the 4-byte entry format applies
                                    // (a count above kPackedCountMax is stored as several entries of the same minor --
@@ -106,6 +116,8 @@ struct Layout {
     std::vector<int32_t> seg_ptr;        // n_segs + 1 : first slice of each segment
     std::vector<int32_t> inv_ptr;        // n_major + 1 : tasks of each major ...
     std::vector<uint32_t> inv_task;      // n_tasks     : ... as slice*64+lane ids, in (block, position) order
+    std::vector<int32_t> cell_perm;      // cells of the column range in layout order: position -> original local column
+                                         // (minors on side 0, majors on side 1; empty = identity).  order.cpp
     BigVec<uint32_t> packed;             // n_slots (wide == false)
     BigVec<uint32_t> wide_idx;           // n_slots (wide == true)
     BigVec<double> wide_val;             // n_slots (wide == true)
@@ -158,13 +170,19 @@ constexpr int sweep_threads(int RT) { return sweep_threads_lane(RT / rank_shares
 // tasks); n_wg <= 0 picks the default (256).
 LayoutParams default_layout_params(int64_t n_major, int64_t n_minor, int R, int n_wg = 0, int64_t nnz = 0);
 
-// Build the layout of `side` for columns [cb, ce) of X.
-int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const LayoutParams &lp, Layout &out);
+// Build the layout of `side` for columns [cb, ce) of X, the cells renumbered by `perm` (position -> local column; null or
+// empty: as stored).  The whole matrix (cb = 0, ce = m) must be given X.cell_order(): the cached row-major copy is in it.
+int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const LayoutParams &lp, const std::vector<int32_t> *perm, Layout &out);
+// order.cpp: the renumbering for columns [cb, ce) (empty: identity / switched off: VBNMF_CELL_ORDER=0; =1 forces it on
+// for every size; default: sparse matrices with at least 8192 cells in the range).
+std::vector<int32_t> compute_cell_order(const Matrix &X, int64_t cb, int64_t ce);
 
 const char *last_error_cstr();
 
+// perm (optional, nouter entries): outer vector p of the result's numbering is input vector perm[p]
 void transpose_compressed(int64_t nouter, int64_t ninner, const int64_t *ptr, const int32_t *idx, const double *val,
-                          int32_t idx_offset, std::vector<int64_t> &tptr, std::vector<int32_t> &tidx, std::vector<double> &tval);
+                          int32_t idx_offset, std::vector<int64_t> &tptr, std::vector<int32_t> &tidx, std::vector<double> &tval,
+                          const int32_t *perm = nullptr);
 
 // Canonical matrix from compressed columns in any order within a column (duplicates summed, zeros dropped).
 int matrix_from_csc(int64_t n, int64_t m, const int32_t *p, const int32_t *i, const double *x, Matrix &X);
@@ -213,6 +231,14 @@ std::shared_ptr<void> cached_device_copy(const vbnmf_matrix *X, const Layout *L,
 void store_device_copy(const vbnmf_matrix *X, const Layout *L, int device, std::shared_ptr<void> arrays);
 // The padded rank whose geometry an engine of padded rank R uses on this matrix (R itself without a plan).
 int plan_class(const vbnmf_matrix *X, int R);
+// Rank classes of a sweep (padded ranks, ascending): the largest planned rank, then up to max_classes - 1 further ones,
+// each the largest planned rank whose LDS rows are at most half as wide as the previous class's.
+std::vector<int32_t> rank_classes(const int32_t *ranks, int32_t count, int32_t max_classes);
+// Persistent workgroups of the sweep on `device` (one per CU; VBNMF_NWG overrides; a partition's sweep leaves
+// VBNMF_COMM_CUS free for the all-reduce kernels).  rc != 0 on a HIP error.  Defined in engine.hip.
+int sweep_workgroups(int device, bool partitioned, int &n_wg);
+// Adds an already built layout to the matrix's cache (imported from another process of the node).
+void cache_layout(const vbnmf_matrix *X, int side, const LayoutParams &lp, std::shared_ptr<const Layout> L);
 }
 struct vbnmf_layout {
     vbnmf::Layout L;

@@ -100,12 +100,36 @@ int dev_upload(T **p, const std::vector<T, A> &v)
 
 }  // namespace
 
+namespace vbnmf {
+int sweep_workgroups(int device, bool partitioned, int &n_wg)
+{
+    hipDeviceProp_t prop;
+    HIPCHECK(hipGetDeviceProperties(&prop, device));
+    n_wg = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;      // one persistent workgroup per CU
+    const char *forced = getenv("VBNMF_NWG");
+    if (forced) { int v = atoi(forced); if (v > 0) n_wg = v; }
+    if (partitioned && !forced) {
+        // A partition's sweep leaves a few CUs free: its workgroups own all 160 KB of a CU's LDS, so the all-reduce
+        // kernels that should run BESIDE the cell-side sweep could not start on a chip filled by it.
+        int spare = 8;
+        if (const char *sv = getenv("VBNMF_COMM_CUS")) spare = atoi(sv);
+        if (spare >= 0 && n_wg - spare >= 8) n_wg -= spare;
+    }
+    return VBNMF_OK;
+}
+}  // namespace vbnmf
+
 struct vbnmf_engine {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int64_t n = 0, m = 0, m_global = 0, nnz = 0;
     int64_t col_begin = 0;            // first cell of this partition (0 for an unpartitioned engine)
+    // The layout's internal renumbering of this engine's cells (csrc/order.cpp): the cell-indexed arrays (lh, llh, eh, dh,
+    // the labels) hold position p = original local column cell_perm[p]; empty = as stored.  Every boundary that takes or
+    // returns cell-indexed data translates through it; d_perm is its device copy (random_state's per-element counters).
+    std::vector<int32_t> cell_perm;
+    int32_t *d_perm = nullptr;
     int32_t *d_ids[2] = {nullptr, nullptr};   // arg-max labels of the cells: current / previous (cluster_changes)
     int ids_cur = 0;
     bool ids_valid = false;
@@ -546,6 +570,27 @@ int wait_result(vbnmf_engine *e)
     return VBNMF_OK;
 }
 
+// hipStreamSynchronize with the bound of wait_timeout_s(): for streams that may sit behind a collective whose peer is
+// gone (partitioned engines).  On a timeout the engine is poisoned like the bounded waits of the step paths.
+int bounded_stream_sync(vbnmf_engine *e, hipStream_t stream, const char *what)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    const double limit = wait_timeout_s();
+    for (long spins = 0;; spins++) {
+        const hipError_t q = hipStreamQuery(stream);
+        if (q == hipSuccess) return VBNMF_OK;
+        if (q != hipErrorNotReady) return fail(VBNMF_ERR_HIP, "%s failed on the device: %s", what, hipGetErrorString(q));
+        if ((spins & 0xFF) == 0xFF) {
+            const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (waited > limit) {
+                e->poisoned = true;
+                return fail(VBNMF_ERR_HIP, "timed out after %.1f s (VBNMF_WAIT_TIMEOUT_S) waiting for %s", waited, what);
+            }
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
+    }
+}
+
 int harvest_timing(vbnmf_engine *e)
 {
     if (e->timing && e->ev_recorded) {
@@ -569,6 +614,11 @@ int harvest_timing(vbnmf_engine *e)
 
 int use_device(const vbnmf_engine *e)
 {
+    // A bounded wait gave up earlier: work may still sit on the engine's streams behind a collective whose peer is gone,
+    // so any call that synchronises (get_state's memcpy, set_state, another run) would block without bound -- the very
+    // hang the timeout exists to prevent.  Every entry point passes through here: fail fast, only destroy is left.
+    if (e->poisoned)
+        return fail(VBNMF_ERR_STATE, "the engine timed out earlier (VBNMF_WAIT_TIMEOUT_S) and may still have work queued; destroy it");
     HIPCHECK(hipSetDevice(e->device));
     return VBNMF_OK;
 }
@@ -642,7 +692,7 @@ void vbnmf_engine_destroy(vbnmf_engine *e)
     (void)hipFree(e->lw); (void)hipFree(e->llw); (void)hipFree(e->ew); (void)hipFree(e->dw);
     (void)hipFree(e->lh); (void)hipFree(e->llh); (void)hipFree(e->eh); (void)hipFree(e->dh);
     (void)hipFree(e->epart); (void)hipFree(e->bpW); (void)hipFree(e->bpH);
-    (void)hipFree(e->d_ids[0]); (void)hipFree(e->d_ids[1]); (void)hipFree(e->d_table); (void)hipFree(e->svd_ws); (void)hipFree(e->svd_status);
+    (void)hipFree(e->d_perm); (void)hipFree(e->d_ids[0]); (void)hipFree(e->d_ids[1]); (void)hipFree(e->d_table); (void)hipFree(e->svd_ws); (void)hipFree(e->svd_status);
     (void)hipFree(e->red); (void)hipFree(e->red_g); (void)hipFree(e->d_out);
     for (hipEvent_t ev : e->ev_ring) (void)hipEventDestroy(ev);
     if (e->cstream) (void)hipStreamDestroy(e->cstream); (void)hipFree(e->dbg); (void)hipFree(e->logtab); (void)hipFree(e->ctl);
@@ -657,24 +707,24 @@ void vbnmf_engine_destroy(vbnmf_engine *e)
     delete e;
 }
 
-int vbnmf_engine_create_part(const vbnmf_matrix *X, int64_t cb, int64_t ce, int64_t m_global, int32_t r,
+// geometry_rank: the rank whose LDS row size the tiled layouts are cut for (>= r: several ranks of a sweep share one pair
+// of layouts); 0: this rank's class in the matrix's plan (vbnmf_matrix_plan_ranks), its own geometry without one.
+int vbnmf_engine_create_geom(const vbnmf_matrix *X, int64_t cb, int64_t ce, int64_t m_global, int32_t r, int32_t geometry_rank,
                              int32_t device, vbnmf_engine **out)
 {
     if (!out) return fail(VBNMF_ERR_BAD_ARG, "out pointer is NULL");
     *out = nullptr;
     if (!X) return fail(VBNMF_ERR_BAD_ARG, "matrix handle is NULL");
     if (r < 1 || r > VBNMF_MAX_RANK) return fail(VBNMF_ERR_BAD_ARG, "rank %d is outside [1, %d]", r, VBNMF_MAX_RANK);
+    if (geometry_rank != 0 && (geometry_rank < r || geometry_rank > VBNMF_MAX_RANK))
+        return fail(VBNMF_ERR_BAD_ARG, "geometry rank %d cannot serve rank %d (it must lie in [rank, %d])", geometry_rank, r, VBNMF_MAX_RANK);
     if (cb < 0 || ce > X->M.m || cb >= ce) return fail(VBNMF_ERR_BAD_ARG, "column range [%lld, %lld) is outside the matrix", (long long)cb, (long long)ce);
     if (m_global < ce - cb) return fail(VBNMF_ERR_BAD_ARG, "m_global is smaller than the partition");
+    if (X->M.shell && !(cb == 0 && ce == X->M.m))
+        return fail(VBNMF_ERR_STATE, "this matrix handle is a shell (vbnmf_matrix_shell): it holds no entries to cut a partition's layout from");
     if (int rc = check_device(device)) return rc;
     HIPCHECK(hipSetDevice(device));
 
-    int n_cu = 256;
-    {
-        hipDeviceProp_t prop;
-        HIPCHECK(hipGetDeviceProperties(&prop, device));
-        if (prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
-    }
     vbnmf_engine *e = new (std::nothrow) vbnmf_engine();
     if (!e) return fail(VBNMF_ERR_OOM, "out of host memory");
     e->device = device;
@@ -691,26 +741,21 @@ int vbnmf_engine_create_part(const vbnmf_matrix *X, int64_t cb, int64_t ce, int6
         e->ub = ub;
     }
     e->wide = !X->M.counts_int;
-    e->n_wg = n_cu;                      // one persistent workgroup per CU
-    if (const char *sv = getenv("VBNMF_NWG")) { int v = atoi(sv); if (v > 0) e->n_wg = v; }
     e->partitioned = (ce - cb) != m_global;
-    if (e->partitioned && !getenv("VBNMF_NWG")) {
-        // A partition's sweep leaves a few CUs free: its workgroups own all 160 KB of a CU's LDS, so the all-reduce
-        // kernels that should run BESIDE the cell-side sweep could not start on a chip filled by it.
-        int spare = 8;
-        if (const char *sv = getenv("VBNMF_COMM_CUS")) spare = atoi(sv);
-        if (spare >= 0 && e->n_wg - spare >= 8) e->n_wg -= spare;
-    }
+    if (int rc = sweep_workgroups(device, e->partitioned, e->n_wg)) { delete e; return rc; }
     int rc = VBNMF_OK;
     auto bail = [&](int code) { vbnmf_engine_destroy(e); return code; };
 
     try {
+        std::vector<int32_t> part_order;                         // a partition orders its own cells (both sides alike)
+        if (!(cb == 0 && ce == X->M.m)) part_order = compute_cell_order(X->M, cb, ce);
         for (int side = 0; side < 2 && !rc; side++) {
             int64_t nmaj = side == 0 ? e->n : e->m, nmin = side == 0 ? e->m : e->n;
             // The geometry is that of the matrix's rank CLASS (vbnmf_matrix_plan_ranks; without a plan the class is this
             // rank's own): the ranks of a sweep share one pair of layouts, cut for the widest rows among them.
-            const int Rc = std::max(e->R, plan_class(X, e->R));
-            LayoutParams lp = default_layout_params(nmaj, nmin, Rc, e->n_wg, X->M.colptr[ce] - X->M.colptr[cb]);
+            const int Rc = geometry_rank ? padded_rank(geometry_rank) : std::max(e->R, plan_class(X, e->R));
+            const int64_t nnz_part = (cb == 0 && ce == X->M.m) ? X->M.nnz : X->M.colptr[ce] - X->M.colptr[cb];
+            LayoutParams lp = default_layout_params(nmaj, nmin, Rc, e->n_wg, nnz_part);
             std::shared_ptr<const Layout> shared;
             Layout own;
             const Layout *L = &own;
@@ -718,18 +763,20 @@ int vbnmf_engine_create_part(const vbnmf_matrix *X, int64_t cb, int64_t ce, int6
                 shared = shared_layout(X, side, lp, rc);
                 L = shared.get();
             } else {
-                rc = build_layout(X->M, cb, ce, side, lp, own);
+                rc = build_layout(X->M, cb, ce, side, lp, &part_order, own);
             }
             if (!rc) rc = upload_side(*L, e->R, device, shared ? X : nullptr, side == 0 ? e->A : e->B);
-            if (!rc && side == 0) e->nnz = L->nnz;
+            if (!rc && side == 0) { e->nnz = L->nnz; e->cell_perm = L->cell_perm; }
+            if (!rc && side == 1 && L->cell_perm != e->cell_perm) rc = fail(VBNMF_ERR_STATE, "the two sides' layouts disagree on the order of the cells");
         }
     } catch (const std::bad_alloc &) {
         rc = fail(VBNMF_ERR_OOM, "out of host memory building the tiled layout");
     }
     if (rc) return bail(rc);
+    if (!e->cell_perm.empty() && (rc = dev_upload(&e->d_perm, e->cell_perm))) return bail(rc);
     e->lgx = (cb == 0 && ce == X->M.m) ? X->lgx : sum_lgamma_x1(X->M, cb, ce);
     if (cb == 0 && ce == X->M.m) {                    // whole matrix: formed once per matrix, not per engine (a pass over X)
-        std::call_once(X->xlx_once, [&] { X->xlx = sum_xlogx(X->M, 0, X->M.m); });
+        std::call_once(X->xlx_once, [&] { X->xlx = sum_xlogx(X->M, 0, X->M.m); });      // (a shell carries the value already)
         e->xlx = X->xlx;
     } else {
         e->xlx = sum_xlogx(X->M, cb, ce);
@@ -782,6 +829,22 @@ int vbnmf_engine_create_part(const vbnmf_matrix *X, int64_t cb, int64_t ce, int6
     return VBNMF_OK;
 }
 
+int vbnmf_engine_create_part(const vbnmf_matrix *X, int64_t cb, int64_t ce, int64_t m_global, int32_t r,
+                             int32_t device, vbnmf_engine **out)
+{
+    return vbnmf_engine_create_geom(X, cb, ce, m_global, r, 0, device, out);
+}
+
+int vbnmf_device_sweep_workgroups(int32_t device, int32_t *n_wg)
+{
+    if (!n_wg) return fail(VBNMF_ERR_BAD_ARG, "NULL argument");
+    if (int rc = check_device(device)) return rc;
+    int v = 0;
+    if (int rc = sweep_workgroups(device, false, v)) return rc;
+    *n_wg = v;
+    return VBNMF_OK;
+}
+
 int vbnmf_engine_create(const vbnmf_matrix *X, int32_t r, int32_t device, vbnmf_engine **out)
 {
     if (!X) { if (out) *out = nullptr; return fail(VBNMF_ERR_BAD_ARG, "matrix handle is NULL"); }
@@ -814,25 +877,34 @@ int vbnmf_engine_set_stream(vbnmf_engine *e, void *stream)
     return VBNMF_OK;
 }
 
-// column-major n x r (R matrix) -> device [n][R]; or r x m column-major (already index-major) -> [m][R]
-static void to_index_major(const double *src, int64_t nmaj, int r, int R, bool src_is_major_contiguous, std::vector<double> &dst)
+// column-major n x r (R matrix) -> device [n][R]; or r x m column-major (already index-major) -> [m][R].
+// perm (cell-indexed arrays only): device row p holds the caller's major perm[p] (the layout's order of the cells).
+static void to_index_major(const double *src, int64_t nmaj, int r, int R, bool src_is_major_contiguous, std::vector<double> &dst,
+                           const std::vector<int32_t> *perm = nullptr)
 {
     dst.assign((size_t)nmaj * R, 0.0);
+    const int32_t *pm = (perm && !perm->empty()) ? perm->data() : nullptr;
     parallel_for(nmaj, [&](int64_t b, int64_t e, int) {
-        for (int64_t M = b; M < e; M++)
+        for (int64_t M = b; M < e; M++) {
+            const int64_t S = pm ? pm[M] : M;
             for (int k = 0; k < r; k++)
-                dst[(size_t)M * R + k] = src_is_major_contiguous ? src[(size_t)M * r + k] : src[M + (size_t)k * nmaj];
+                dst[(size_t)M * R + k] = src_is_major_contiguous ? src[(size_t)S * r + k] : src[S + (size_t)k * nmaj];
+        }
     });
 }
 
-static void from_index_major(const std::vector<double> &src, int64_t nmaj, int r, int R, bool dst_is_major_contiguous, double *dst)
+static void from_index_major(const std::vector<double> &src, int64_t nmaj, int r, int R, bool dst_is_major_contiguous, double *dst,
+                             const std::vector<int32_t> *perm = nullptr)
 {
+    const int32_t *pm = (perm && !perm->empty()) ? perm->data() : nullptr;
     parallel_for(nmaj, [&](int64_t b, int64_t e, int) {
-        for (int64_t M = b; M < e; M++)
+        for (int64_t M = b; M < e; M++) {
+            const int64_t D = pm ? pm[M] : M;
             for (int k = 0; k < r; k++) {
                 double v = src[(size_t)M * R + k];
-                if (dst_is_major_contiguous) dst[(size_t)M * r + k] = v; else dst[M + (size_t)k * nmaj] = v;
+                if (dst_is_major_contiguous) dst[(size_t)D * r + k] = v; else dst[D + (size_t)k * nmaj] = v;
             }
+        }
     });
 }
 
@@ -847,10 +919,10 @@ int vbnmf_engine_set_state(vbnmf_engine *e, const double *lw, const double *lh, 
         to_index_major(lw, e->n, e->r, e->R, false, tmp);
         HIPCHECK(hipMemcpyAsync(e->lw, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
         HIPCHECK(hipStreamSynchronize(e->stream));
-        to_index_major(lh, e->m, e->r, e->R, true, tmp);
+        to_index_major(lh, e->m, e->r, e->R, true, tmp, &e->cell_perm);
         HIPCHECK(hipMemcpyAsync(e->lh, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
         HIPCHECK(hipStreamSynchronize(e->stream));
-        to_index_major(eh, e->m, e->r, e->R, true, tmp);
+        to_index_major(eh, e->m, e->r, e->R, true, tmp, &e->cell_perm);
         HIPCHECK(hipMemcpyAsync(e->eh, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
         HIPCHECK(hipStreamSynchronize(e->stream));
     } catch (const std::bad_alloc &) {
@@ -870,9 +942,9 @@ int vbnmf_engine_random_state(vbnmf_engine *e, double aw, double bw, double ah, 
     e->ml_ready = false; e->ids_valid = false;
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     const int64_t nw = e->n * e->R, nh = e->m * e->R;
-    hipLaunchKernelGGL(k_gamma_init, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, e->stream, e->lw, e->ew, e->dw, e->n, (int64_t)0, e->r, e->R, aw, bw, 0u, k0, k1);
+    hipLaunchKernelGGL(k_gamma_init, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, e->stream, e->lw, e->ew, e->dw, e->n, (int64_t)0, e->r, e->R, aw, bw, 0u, k0, k1, (const int32_t *)nullptr);
     HIPCHECK(hipGetLastError());
-    hipLaunchKernelGGL(k_gamma_init, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, e->stream, e->lh, e->eh, e->dh, e->m, e->col_begin, e->r, e->R, ah, bh, 1u, k0, k1);
+    hipLaunchKernelGGL(k_gamma_init, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, e->stream, e->lh, e->eh, e->dh, e->m, e->col_begin, e->r, e->R, ah, bh, 1u, k0, k1, (const int32_t *)e->d_perm);
     HIPCHECK(hipGetLastError());
     return prime_state(e);
 }
@@ -882,7 +954,11 @@ int vbnmf_engine_state_finish(vbnmf_engine *e)
     if (!e) return fail(VBNMF_ERR_BAD_ARG, "engine handle is NULL");
     if (!e->prime_pending) return fail(VBNMF_ERR_STATE, "state_finish without a pending set_state");
     if (int rc = use_device(e)) return rc;
-    HIPCHECK(hipStreamSynchronize(e->stream));
+    if (e->partitioned) {                            // the state exchange sits on this stream: a peer that never joins it must not hang us
+        if (int rc = bounded_stream_sync(e, e->stream, "the state exchange of a partitioned engine")) return rc;
+    } else {
+        HIPCHECK(hipStreamSynchronize(e->stream));
+    }
     if (int rc = harvest_timing(e)) return rc;
     e->sweep_ms = 0.0; e->sweep_launches = 0;        // the priming sweep is not a step
     e->prime_pending = false;
@@ -893,9 +969,9 @@ int vbnmf_engine_state_finish(vbnmf_engine *e)
 int vbnmf_engine_step_local(vbnmf_engine *e, double aw, double bw, double ah, double bh, double fudge)
 {
     if (!e) return fail(VBNMF_ERR_BAD_ARG, "engine handle is NULL");
+    if (int rc = use_device(e)) return rc;                                   // (first: an engine that timed out says so, whatever its state)
     if (!e->has_state || !e->stats_ready) return fail(VBNMF_ERR_STATE, "step before set_state (or before state_finish on a partitioned engine)");
     if (e->step_pending) return fail(VBNMF_ERR_STATE, "step_local called twice without step_finish");
-    if (int rc = use_device(e)) return rc;
     if (int rc = launch_update(e, true, aw, bw, fudge)) return rc;
     if (int rc = launch_update(e, false, ah, bh, fudge)) return rc;
     if (int rc = launch_sweep(e)) return rc;
@@ -915,8 +991,8 @@ int vbnmf_engine_reduce_buffer(vbnmf_engine *e, void **device_ptr, int64_t *coun
 int vbnmf_engine_step_finish(vbnmf_engine *e, double *lkh, double *stats)
 {
     if (!e) return fail(VBNMF_ERR_BAD_ARG, "engine handle is NULL");
-    if (!e->step_pending) return fail(VBNMF_ERR_STATE, "step_finish without step_local");
     if (int rc = use_device(e)) return rc;
+    if (!e->step_pending) return fail(VBNMF_ERR_STATE, "step_finish without step_local");
     if (int rc = launch_final(e)) return rc;
     if (int rc = wait_result(e)) return rc;
     e->step_pending = false;
@@ -1141,7 +1217,7 @@ int queue_vb_step(const LoopGroup &G, double fudge, bool hist, int max_it)
 // therefore queues the same number of steps, i.e. the same sequence of collectives.  The host reads the pinned result
 // block of engine 0: [5] = steps done, [6] = reason (raised after [5]), [7] = steps done (raised last).
 template <class QueueStep>
-int drive_loop(vbnmf_engine *e0, int max_it, QueueStep &&queue_step)
+int drive_loop(vbnmf_engine *e0, int max_it, bool fold, QueueStep &&queue_step)
 {
     volatile double *ho = e0->h_out;
     const int B = 8;
@@ -1151,12 +1227,31 @@ int drive_loop(vbnmf_engine *e0, int max_it, QueueStep &&queue_step)
             if (int rc = queue_step()) return rc;
         return VBNMF_OK;
     };
+    // "The stream is idle, no stop was raised, and fewer steps are reported than a drained stream must show": something
+    // was lost on the device.  With the control step folded into the NEXT step's update (ControlFold / MlFold) step t is
+    // only reported by step t + 1's launch, so a fully drained, healthy stream shows queued - 1 until the closing
+    // control-only launch behind step max_it has been queued.
+    auto idle_check = [&]() -> int {
+        hipError_t q = hipStreamQuery(e0->stream);
+        if (q != hipSuccess && q != hipErrorNotReady) return fail(VBNMF_ERR_HIP, "the loop failed on the device: %s", hipGetErrorString(q));
+        const int expect = queued - ((fold && queued < max_it) ? 1 : 0);
+        if (q == hipSuccess && ho[6] == 0.0 && (int)ho[7] < expect) return fail(VBNMF_ERR_HIP, "the device went idle before the queued steps finished");
+        return VBNMF_OK;
+    };
+    // test hook (tests/test_gpu_control_fold.py): drain the stream before every look, i.e. the host thread stalled between
+    // queueing and polling -- the case the idle check must not mistake for a lost step
+    const char *drain_env = getenv("VBNMF_TEST_DRAIN_BEFORE_POLL");
+    const bool drain_first = drain_env && drain_env[0] == '1';
     if (int rc = queue_batch()) return rc;
     if (int rc = queue_batch()) return rc;
     const double limit = wait_timeout_s();
     for (int b = 0;; b++) {
         const int target = (int)std::min<int64_t>((int64_t)(b + 1) * B, max_it);
         const auto t0 = std::chrono::steady_clock::now();          // the bound is per batch of B steps
+        if (drain_first) {
+            (void)hipStreamSynchronize(e0->stream);
+            if (int rc = idle_check()) return rc;
+        }
         for (long spins = 1; ho[6] == 0.0 && (int)ho[7] < target; spins++) {
             if ((spins & 0xFFFF) == 0) {
                 const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -1165,9 +1260,7 @@ int drive_loop(vbnmf_engine *e0, int max_it, QueueStep &&queue_step)
                     return fail(VBNMF_ERR_HIP, "timed out after %.1f s (VBNMF_WAIT_TIMEOUT_S) waiting for step %d of the device-driven loop; "
                                 "the last completed step is %d (%d queued)", waited, target, (int)ho[7], queued);
                 }
-                hipError_t q = hipStreamQuery(e0->stream);
-                if (q != hipSuccess && q != hipErrorNotReady) return fail(VBNMF_ERR_HIP, "the loop failed on the device: %s", hipGetErrorString(q));
-                if (q == hipSuccess && ho[6] == 0.0 && (int)ho[7] < queued) return fail(VBNMF_ERR_HIP, "the device went idle before the queued steps finished");
+                if (int rc = idle_check()) return rc;
             }
         }
         if (ho[6] != 0.0 && (int)ho[5] <= target) break;        // stopped inside a batch that is complete
@@ -1186,6 +1279,7 @@ int run_group(const LoopGroup &G, double *hyper, double fudge, int32_t max_it, d
     if (history && history_rows < max_it) return fail(VBNMF_ERR_BAD_ARG, "history needs max_it rows of 9 doubles");
     for (int p = 0; p < G.count; p++) {
         vbnmf_engine *e = G.e[p];
+        if (int rc = use_device(e)) return rc;
         if (!e->has_state || !e->stats_ready) return fail(VBNMF_ERR_STATE, "run before set_state (or before the state exchange of a partitioned engine)");
         if (e->step_pending) return fail(VBNMF_ERR_STATE, "run between step_local and step_finish");
     }
@@ -1236,7 +1330,7 @@ int run_group(const LoopGroup &G, double *hyper, double fudge, int32_t max_it, d
     hipError_t he = hipGetLastError();
     if (he != hipSuccess) return cleanup(fail(VBNMF_ERR_HIP, "loading the loop control block failed: %s", hipGetErrorString(he)));
 
-    int rc = drive_loop(e0, max_it, [&]() { return queue_vb_step(G, fudge, history != nullptr, max_it); });
+    int rc = drive_loop(e0, max_it, !G.comm && e0->fold, [&]() { return queue_vb_step(G, fudge, history != nullptr, max_it); });
     if (rc) return cleanup(rc);
     for (int p = 0; p < G.count; p++) {
         he = hipStreamSynchronize(G.e[p]->stream);
@@ -1439,7 +1533,7 @@ int vbnmf_engine_get_state(vbnmf_engine *e, double *lw, double *lh, double *ew, 
             const int64_t nmaj = it.gene ? e->n : e->m;
             tmp.resize((size_t)nmaj * e->R);
             HIPCHECK(hipMemcpy(tmp.data(), it.src, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
-            from_index_major(tmp, nmaj, e->r, e->R, !it.gene, it.dst);
+            from_index_major(tmp, nmaj, e->r, e->R, !it.gene, it.dst, it.gene ? nullptr : &e->cell_perm);
         }
     } catch (const std::bad_alloc &) {
         return fail(VBNMF_ERR_OOM, "out of host memory staging the state");
@@ -1507,7 +1601,7 @@ int vbnmf_engine_ml_set_state(vbnmf_engine *e, const double *w, const double *h)
         to_index_major(w, e->n, e->r, e->R, false, tmp);
         HIPCHECK(hipMemcpyAsync(e->lw, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
         HIPCHECK(hipStreamSynchronize(e->stream));
-        to_index_major(h, e->m, e->r, e->R, true, tmp);
+        to_index_major(h, e->m, e->r, e->R, true, tmp, &e->cell_perm);
         HIPCHECK(hipMemcpyAsync(e->lh, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
         HIPCHECK(hipStreamSynchronize(e->stream));
     } catch (const std::bad_alloc &) {
@@ -1597,7 +1691,7 @@ int vbnmf_engine_ml_run(vbnmf_engine *e, int32_t prior, double gamma_a, double g
         return rc;
     };
     double *hist_dev = history ? e->h_hist_dev : nullptr;
-    int rc = drive_loop(e, max_it, [&]() -> int {
+    int rc = drive_loop(e, max_it, e->fold, [&]() -> int {
         if (e->fold) {
             // k_ml_update(H, with the control step of the PREVIOUS cell-side sweep folded in)  sweep  k_ml_update(W)  sweep ;
             // behind the last step of the run the control step alone (mlnmf.h: MlFold)
@@ -1669,7 +1763,7 @@ int vbnmf_engine_ml_get_state(vbnmf_engine *e, double *w, double *h)
         if (h) {
             tmp.resize((size_t)e->m * e->R);
             HIPCHECK(hipMemcpy(tmp.data(), e->lh, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
-            from_index_major(tmp, e->m, e->r, e->R, true, h);
+            from_index_major(tmp, e->m, e->r, e->R, true, h, &e->cell_perm);
         }
     } catch (const std::bad_alloc &) {
         return fail(VBNMF_ERR_OOM, "out of host memory staging the state");
@@ -1687,10 +1781,14 @@ int vbnmf_engine_cluster_ids(vbnmf_engine *e, int32_t *ids)
     if (int rc = dev_alloc(&d_ids, (size_t)e->m)) return rc;
     hipLaunchKernelGGL(k_argmax, dim3((unsigned)((e->m + 255) / 256)), dim3(256), 0, e->stream, h, e->m, e->r, e->R, d_ids);
     hipError_t he = hipGetLastError();
-    if (he == hipSuccess) he = hipMemcpyAsync(ids, d_ids, (size_t)e->m * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream);
+    std::vector<int32_t> stage;
+    int32_t *host = ids;
+    if (!e->cell_perm.empty()) { stage.resize((size_t)e->m); host = stage.data(); }      // labels arrive in the layout's cell order
+    if (he == hipSuccess) he = hipMemcpyAsync(host, d_ids, (size_t)e->m * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream);
     if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
     (void)hipFree(d_ids);
     if (he != hipSuccess) return fail(VBNMF_ERR_HIP, "cluster_ids failed: %s", hipGetErrorString(he));
+    if (!e->cell_perm.empty()) for (int64_t p = 0; p < e->m; p++) ids[e->cell_perm[p]] = stage[p];
     return VBNMF_OK;
 }
 
@@ -1720,8 +1818,12 @@ int vbnmf_engine_cluster_changes(vbnmf_engine *e, int64_t *changed, int32_t *ids
         HIPCHECK(hipGetLastError());
         HIPCHECK(hipMemcpyAsync(&n, e->d_table + (tcount - 1), sizeof n, hipMemcpyDeviceToHost, e->stream));
     }
-    if (ids) HIPCHECK(hipMemcpyAsync(ids, e->d_ids[cur], (size_t)e->m * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+    std::vector<int32_t> stage;
+    int32_t *host = ids;
+    if (ids && !e->cell_perm.empty()) { stage.resize((size_t)e->m); host = stage.data(); }
+    if (ids) HIPCHECK(hipMemcpyAsync(host, e->d_ids[cur], (size_t)e->m * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
     HIPCHECK(hipStreamSynchronize(e->stream));
+    if (ids && !e->cell_perm.empty()) for (int64_t p = 0; p < e->m; p++) ids[e->cell_perm[p]] = stage[p];
     *changed = e->ids_valid ? (int64_t)n : -1;
     e->ids_cur = cur;
     e->ids_valid = true;
@@ -1894,7 +1996,10 @@ int vbnmf_engine_svd(vbnmf_engine *e, int32_t rank_out, double tol, int32_t maxi
         HIPCHECK(hipMemcpy(tmp.data(), e->ew, (size_t)e->n * e->R * sizeof(double), hipMemcpyDeviceToHost));
         for (int64_t i = 0; i < e->n; i++) for (int q = 0; q < rank_out; q++) u[i + (size_t)q * e->n] = tmp[(size_t)i * e->R + q];
         HIPCHECK(hipMemcpy(tmp.data(), e->eh, (size_t)e->m * e->R * sizeof(double), hipMemcpyDeviceToHost));
-        for (int64_t j = 0; j < e->m; j++) for (int q = 0; q < rank_out; q++) vt[q + (size_t)j * rank_out] = tmp[(size_t)j * e->R + q];
+        for (int64_t j = 0; j < e->m; j++) {
+            const int64_t col = e->cell_perm.empty() ? j : e->cell_perm[j];
+            for (int q = 0; q < rank_out; q++) vt[q + (size_t)col * rank_out] = tmp[(size_t)j * e->R + q];
+        }
     } catch (const std::bad_alloc &) {
         return fail(VBNMF_ERR_OOM, "out of host memory staging the singular vectors");
     }
@@ -1916,7 +2021,7 @@ int vbnmf_engine_spmm(vbnmf_engine *e, int32_t transpose, const double *B, doubl
     double *dense = gene_side ? e->ew : e->eh;         // [n_out][R] result before the download
     try {
         std::vector<double> tmp;
-        to_index_major(B, n_in, e->r, e->R, gene_side, tmp);
+        to_index_major(B, n_in, e->r, e->R, gene_side, tmp, gene_side ? &e->cell_perm : nullptr);     // B: one row per cell on the gene side
         HIPCHECK(hipMemcpyAsync(operand, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
         HIPCHECK(hipStreamSynchronize(e->stream));
         SweepSide a = sweep_side_args(e, gene_side ? e->A : e->B, gene_side, gene_side ? e->epart : e->epart + e->n_wg);
@@ -1937,7 +2042,7 @@ int vbnmf_engine_spmm(vbnmf_engine *e, int32_t transpose, const double *B, doubl
         tmp.resize((size_t)cnt);
         HIPCHECK(hipMemcpyAsync(tmp.data(), dense, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
         HIPCHECK(hipStreamSynchronize(e->stream));
-        from_index_major(tmp, n_out, e->r, e->R, !gene_side, C);
+        from_index_major(tmp, n_out, e->r, e->R, !gene_side, C, gene_side ? nullptr : &e->cell_perm);
     } catch (const std::bad_alloc &) {
         return fail(VBNMF_ERR_OOM, "out of host memory staging the operands");
     }
@@ -2008,6 +2113,12 @@ int vbnmf_test_stream_sleep(vbnmf_engine *e, double seconds)
 // ---------------------------------------------------------------- stateless forms
 }  // extern "C"
 
+namespace { uint64_t hash_bytes(const void *data, size_t bytes, uint64_t seed); }
+extern "C" {
+// Test hook (no device needed): the content hash of the stateless cache, for tests/test_cabi_symbols.py.
+uint64_t vbnmf_test_hash_bytes(const void *data, int64_t bytes, uint64_t seed) { return (data && bytes >= 0) ? hash_bytes(data, (size_t)bytes, seed) : 0; }
+}
+
 namespace {
 
 // The reference's caller hands the SAME X to every one of its thousands of calls (R/bayesian.R:339).  The stateless
@@ -2022,6 +2133,7 @@ struct StatelessCache {
     int64_t n = 0, m = 0, nnz = 0;
     uint64_t hash = 0, hash2 = 0;     // two independently seeded 64-bit hashes of the content: a 128-bit key
     std::vector<int32_t> colptr;      // csc: a copy of the pointer array, compared on a hit (not only hashed)
+    std::vector<double> sample;       // dense: a strided sample of X (<= 4096 values), compared on a hit as well
     vbnmf_matrix *X = nullptr;
     vbnmf_engine *e = nullptr;
     int r = 0;
@@ -2031,13 +2143,16 @@ struct StatelessCache {
         vbnmf_matrix_destroy(X); X = nullptr;
         valid = false;
         colptr.clear();
+        sample.clear();
     }
 };
 StatelessCache &stateless_cache() { static StatelessCache c; return c; }
 
 uint64_t hash_bytes(const void *data, size_t bytes, uint64_t seed)
 {
-    // per-chunk multiply-xorshift over 8-byte words, chunks combined in order: independent of the thread count
+    // per-chunk multiply-xorshift over 8-byte words, chunks combined in order: independent of the thread count.  The seed
+    // starts every chunk's digest (not only the final combine), so two seeds give two INDEPENDENT 64-bit hashes: contents
+    // that collide in a chunk digest under one seed do not under the other (tests/test_cabi_symbols.py).
     const size_t chunk = (size_t)1 << 22;
     const size_t nchunks = (bytes + chunk - 1) / chunk;
     std::vector<uint64_t> part(nchunks ? nchunks : 1, 0);
@@ -2045,7 +2160,7 @@ uint64_t hash_bytes(const void *data, size_t bytes, uint64_t seed)
     parallel_for((int64_t)nchunks, [&](int64_t b, int64_t e, int) {
         for (int64_t c = b; c < e; c++) {
             const size_t o = (size_t)c * chunk, len = std::min(chunk, bytes - o);
-            uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)c;
+            uint64_t h = seed ^ 0x9E3779B97F4A7C15ull ^ ((uint64_t)c * 0xD6E8FEB86659FD93ull);   // the seed enters EVERY chunk digest
             size_t q = 0;
             for (; q + 8 <= len; q += 8) {
                 uint64_t w;
@@ -2069,17 +2184,25 @@ bool stateless_cache_enabled()
 }
 
 // The engine of rank r on the matrix with this key: from the cache, or ingested now through `ingest`.
-int stateless_engine(int kind, int64_t n, int64_t m, int64_t nnz, uint64_t hash, uint64_t hash2, const int32_t *colptr, int32_t r,
+int stateless_engine(int kind, int64_t n, int64_t m, int64_t nnz, uint64_t hash, uint64_t hash2, const int32_t *colptr, const double *dense, int32_t r,
                      const std::function<int(vbnmf_matrix **)> &ingest, vbnmf_engine **out)
 {
     StatelessCache &C = stateless_cache();
     bool hit = C.valid && C.kind == kind && C.n == n && C.m == m && C.nnz == nnz && C.hash == hash && C.hash2 == hash2;
     if (hit && colptr) hit = C.colptr.size() == (size_t)m + 1 && std::memcmp(C.colptr.data(), colptr, ((size_t)m + 1) * sizeof(int32_t)) == 0;
+    // dense: every 1/4096-th value (an odd stride, so the sample walks through all rows) beside the two hashes
+    const size_t total = dense ? (size_t)n * (size_t)m : 0, stride = std::max<size_t>(1, total / 4096) | 1;
+    if (hit && dense) {
+        size_t q = 0;
+        for (size_t o = 0; o < total && hit; o += stride, q++) hit = q < C.sample.size() && std::memcmp(&C.sample[q], dense + o, sizeof(double)) == 0;
+        hit = hit && q == C.sample.size();
+    }
     if (!hit) {
         C.drop();
         if (int rc = ingest(&C.X)) { C.X = nullptr; return rc; }
         C.kind = kind; C.n = n; C.m = m; C.nnz = nnz; C.hash = hash; C.hash2 = hash2; C.valid = true;
         if (colptr) C.colptr.assign(colptr, colptr + m + 1);
+        if (dense) for (size_t o = 0; o < total; o += stride) C.sample.push_back(dense[o]);
     }
     if (!C.e || C.r != r) {
         vbnmf_engine_destroy(C.e); C.e = nullptr;
@@ -2120,7 +2243,7 @@ int with_dense(int64_t n, int64_t m, int32_t r, const double *X, const std::func
     const uint64_t h2 = cache ? hash_bytes(X, (size_t)n * (size_t)m * sizeof(double), 0x3243F6A8885A308Dull) : 0;
     if (!cache) C.drop();
     vbnmf_engine *e = nullptr;
-    int rc = stateless_engine(0, n, m, 0, h, h2, nullptr, r, [&](vbnmf_matrix **M) { return vbnmf_matrix_from_dense(n, m, X, M); }, &e);
+    int rc = stateless_engine(0, n, m, 0, h, h2, nullptr, X, r, [&](vbnmf_matrix **M) { return vbnmf_matrix_from_dense(n, m, X, M); }, &e);
     if (!rc) rc = use(e);
     if (!cache || rc) C.drop();
     return rc;
@@ -2148,7 +2271,7 @@ int with_csc(int64_t n, int64_t m, int32_t r, const int32_t *p, const int32_t *i
     }
     if (!cache) C.drop();
     vbnmf_engine *e = nullptr;
-    int rc = stateless_engine(1, n, m, nnz, h, h2, p, r, [&](vbnmf_matrix **M) { return vbnmf_matrix_from_csc(n, m, p, i, x, M); }, &e);
+    int rc = stateless_engine(1, n, m, nnz, h, h2, p, nullptr, r, [&](vbnmf_matrix **M) { return vbnmf_matrix_from_csc(n, m, p, i, x, M); }, &e);
     if (!rc) rc = use(e);
     if (!cache || rc) C.drop();
     return rc;

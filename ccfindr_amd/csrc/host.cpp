@@ -101,7 +101,9 @@ static void finish_matrix(Matrix &X)
 const RowMajor &Matrix::row_major() const
 {
     std::call_once(rm_cache->once, [&] {
-        transpose_compressed(m, n, colptr.data(), row.data(), val.data(), 0, rm_cache->rm.ptr, rm_cache->rm.idx, rm_cache->rm.val);
+        const std::vector<int32_t> &perm = cell_order();
+        transpose_compressed(m, n, colptr.data(), row.data(), val.data(), 0, rm_cache->rm.ptr, rm_cache->rm.idx, rm_cache->rm.val,
+                             perm.empty() ? nullptr : perm.data());
     });
     return rm_cache->rm;
 }
@@ -203,18 +205,21 @@ int matrix_from_csc(int64_t n, int64_t m, const int32_t *p, const int32_t *i, co
 // result ascending).  Outer vectors are cut into one chunk per thread; each chunk counts its entries per inner
 // index, an exclusive scan over (inner index, chunk) gives every chunk its write positions, then the chunks scatter.
 void transpose_compressed(int64_t nouter, int64_t ninner, const int64_t *ptr, const int32_t *idx, const double *val,
-                          int32_t idx_offset, std::vector<int64_t> &tptr, std::vector<int32_t> &tidx, std::vector<double> &tval)
+                          int32_t idx_offset, std::vector<int64_t> &tptr, std::vector<int32_t> &tidx, std::vector<double> &tval,
+                          const int32_t *perm)
 {
     const int64_t s = ptr[0], t = ptr[nouter];
     int T = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), (t - s) / (1 << 18) + 1));
     while (T > 1 && (int64_t)T * ninner > (int64_t)1 << 28) T /= 2;             // cap the counter table at 2 GiB
     std::vector<int64_t> cut(T + 1);
     for (int c = 0; c <= T; c++) cut[c] = nouter * c / T;
+    auto src = [&](int64_t j) { return perm ? (int64_t)perm[j] : j; };          // input vector stored at position j
     std::vector<int64_t> cnt((size_t)T * ninner, 0);
     parallel_for(T, [&](int64_t b, int64_t e, int) {
         for (int64_t c = b; c < e; c++) {
             int64_t *my = &cnt[(size_t)c * ninner];
-            for (int64_t q = ptr[cut[c]]; q < ptr[cut[c + 1]]; q++) my[idx[q]]++;
+            for (int64_t j = cut[c]; j < cut[c + 1]; j++)
+                for (int64_t q = ptr[src(j)]; q < ptr[src(j) + 1]; q++) my[idx[q]]++;
         }
     }, T);
     tptr.assign(ninner + 1, 0);
@@ -230,7 +235,7 @@ void transpose_compressed(int64_t nouter, int64_t ninner, const int64_t *ptr, co
         for (int64_t c = b; c < e; c++) {
             int64_t *cur = &cnt[(size_t)c * ninner];
             for (int64_t j = cut[c]; j < cut[c + 1]; j++)
-                for (int64_t q = ptr[j]; q < ptr[j + 1]; q++) {
+                for (int64_t q = ptr[src(j)]; q < ptr[src(j) + 1]; q++) {
                     const int64_t o = cur[idx[q]]++;
                     tidx[o] = (int32_t)(j - idx_offset);
                     tval[o] = val[q];
@@ -361,8 +366,10 @@ LayoutParams default_layout_params(int64_t n_major, int64_t n_minor, int R, int 
     return lp;
 }
 
-int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const LayoutParams &lp, Layout &L)
+int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const LayoutParams &lp, const std::vector<int32_t> *perm_in, Layout &L)
 {
+    const int32_t *perm = (perm_in && !perm_in->empty()) ? perm_in->data() : nullptr;
+    if (perm && (int64_t)perm_in->size() != ce - cb) return fail(VBNMF_ERR_BAD_ARG, "cell order has %lld entries for %lld cells", (long long)perm_in->size(), (long long)(ce - cb));
     if (cb < 0 || ce > X.m || cb >= ce) return fail(VBNMF_ERR_BAD_ARG, "column range [%lld, %lld) is outside the matrix", (long long)cb, (long long)ce);
     // (max_len <= 0x7FF8: the two leading-stretch lengths of a slice share one int32, 15 + 16 bits -- slice_fast below)
     if (lp.block_width <= 0 || lp.block_width > 65536 || lp.max_len <= 0 || lp.max_len > 0x7FF8 || lp.max_len % kWidthQuantum || lp.n_wg <= 0 || lp.row_slots <= 0 ||
@@ -375,26 +382,38 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
     std::vector<int64_t> tptr;
     std::vector<int32_t> tidx;
     std::vector<double> tval;
-    const int64_t *ptr;
+    // entries of major M: [pb[M], pe[M]) of idx / val.  Contiguous majors: pb = ptr, pe = ptr + 1; the cell side under a
+    // renumbering of the cells walks the columns in the new order through two index arrays instead (no copy of X).
+    const int64_t *pb, *pe;
     const int32_t *idx;
     const double *val;
+    std::vector<int64_t> obeg, oend;
     if (side == 1) {
         L.n_major = ce - cb; L.n_minor = X.n;
-        ptr = X.colptr.data() + cb; idx = X.row.data(); val = X.val.data();
+        idx = X.row.data(); val = X.val.data();
+        if (perm) {
+            obeg.resize(ce - cb); oend.resize(ce - cb);
+            for (int64_t p = 0; p < ce - cb; p++) { obeg[p] = X.colptr[cb + perm[p]]; oend[p] = X.colptr[cb + perm[p] + 1]; }
+            pb = obeg.data(); pe = oend.data();
+        } else {
+            pb = X.colptr.data() + cb; pe = pb + 1;
+        }
     } else {
         L.n_major = X.n; L.n_minor = ce - cb;
         if (cb == 0 && ce == X.m) {
-            const RowMajor &Rm = X.row_major();               // built once per matrix, shared by every engine on it
-            ptr = Rm.ptr.data(); idx = Rm.idx.data(); val = Rm.val.data();
+            const RowMajor &Rm = X.row_major();               // built once per matrix (in the matrix's cell order), shared by every engine on it
+            pb = Rm.ptr.data(); idx = Rm.idx.data(); val = Rm.val.data();
         } else {
-            transpose_compressed(ce - cb, X.n, X.colptr.data() + cb, X.row.data(), X.val.data(), 0, tptr, tidx, tval);
-            ptr = tptr.data(); idx = tidx.data(); val = tval.data();
+            transpose_compressed(ce - cb, X.n, X.colptr.data() + cb, X.row.data(), X.val.data(), 0, tptr, tidx, tval, perm);
+            pb = tptr.data(); idx = tidx.data(); val = tval.data();
         }
+        pe = pb + 1;
     }
+    if (perm) L.cell_perm.assign(perm, perm + (ce - cb));
     lap("transpose");
     L.side = side;
     L.wide = !X.counts_int;
-    L.nnz = ptr[L.n_major] - ptr[0];                     // stored entries of X (before any splitting below)
+    L.nnz = X.colptr[ce] - X.colptr[cb];                 // stored entries of X (before any splitting below)
     // integer counts above the packed range: the entry is stored as ceil(x / kPackedCountMax) entries of the same minor
     std::vector<int64_t> xptr;
     std::vector<int32_t> xidx;
@@ -404,14 +423,14 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
         xptr.assign(nm + 1, 0);
         for (int64_t M = 0; M < nm; M++) {
             int64_t c = 0;
-            for (int64_t q = ptr[M]; q < ptr[M + 1]; q++) c += (int64_t)std::ceil(val[q] / kPackedCountMax);
+            for (int64_t q = pb[M]; q < pe[M]; q++) c += (int64_t)std::ceil(val[q] / kPackedCountMax);
             xptr[M + 1] = xptr[M] + c;
         }
         xidx.resize(xptr[nm]); xval.resize(xptr[nm]);
         parallel_for(nm, [&](int64_t b, int64_t e, int) {
             for (int64_t M = b; M < e; M++) {
                 int64_t o = xptr[M];
-                for (int64_t q = ptr[M]; q < ptr[M + 1]; q++) {
+                for (int64_t q = pb[M]; q < pe[M]; q++) {
                     double left = val[q];
                     while (left > 0.0) {
                         const double piece = std::min(left, kPackedCountMax);
@@ -421,7 +440,7 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
                 }
             }
         });
-        ptr = xptr.data(); idx = xidx.data(); val = xval.data();
+        pb = xptr.data(); pe = pb + 1; idx = xidx.data(); val = xval.data();
     }
     L.max_len = lp.max_len;
     L.n_wg = lp.n_wg;
@@ -444,7 +463,8 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
             parallel_for(nmaj, [&](int64_t b, int64_t e, int tid) {
                 std::vector<int64_t> &c = part[tid];
                 c.assign(L.n_minor, 0);
-                for (int64_t q = ptr[b]; q < ptr[e]; q++) c[idx[q]]++;
+                for (int64_t M = b; M < e; M++)
+                    for (int64_t q = pb[M]; q < pe[M]; q++) c[idx[q]]++;
             }, T);
             for (const auto &c : part)
                 if (!c.empty()) for (int64_t j = 0; j < L.n_minor; j++) mcount[j + 1] += c[j];
@@ -488,7 +508,7 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
     std::vector<int64_t> bpos((size_t)nmaj * (nblk + 1));
     parallel_for(nmaj, [&](int64_t b, int64_t e, int) {
         for (int64_t M = b; M < e; M++) {
-            int64_t q = ptr[M], t = ptr[M + 1];
+            int64_t q = pb[M], t = pe[M];
             int64_t *bp = &bpos[(size_t)M * (nblk + 1)];
             for (int32_t blk = 0; blk <= nblk; blk++) {
                 int64_t lim = bstart[blk];
@@ -911,8 +931,14 @@ std::shared_ptr<const Layout> shared_layout(const vbnmf_matrix *X, int side, con
                 return hit.layout;
             }
     }
+    if (X->M.shell) {
+        rc = fail(VBNMF_ERR_STATE, "this matrix handle is a shell (vbnmf_matrix_shell): it holds no entries and no imported layout of side %d "
+                  "for this geometry (block %d, row stride %d slots, %d workgroups); import it with vbnmf_matrix_import_layout", side,
+                  lp.block_width, lp.row_slots, lp.n_wg);
+        return nullptr;
+    }
     auto L = std::make_shared<Layout>();
-    rc = build_layout(X->M, 0, X->M.m, side, lp, *L);
+    rc = build_layout(X->M, 0, X->M.m, side, lp, &X->M.cell_order(), *L);
     if (rc) return nullptr;
     if (cap > 0) {
         std::lock_guard<std::mutex> g(C.mu);
@@ -925,6 +951,51 @@ std::shared_ptr<const Layout> shared_layout(const vbnmf_matrix *X, int side, con
         }
     }
     return L;
+}
+
+void cache_layout(const vbnmf_matrix *X, int side, const LayoutParams &lp, std::shared_ptr<const Layout> L)
+{
+    // an imported layout is kept whatever VBNMF_LAYOUT_CACHE says (a shell cannot rebuild it); it counts towards the cap
+    const int cap = std::max(2, 2 * std::max(0, env_int("VBNMF_LAYOUT_CACHE", 3)));
+    LayoutCache &C = X->layouts;
+    std::lock_guard<std::mutex> g(C.mu);
+    for (size_t i = 0; i < C.entries.size();) {
+        const auto &q = C.entries[i];
+        const bool same = q.side == side && q.lp.block_width == lp.block_width && q.lp.block_cap == lp.block_cap && q.lp.max_len == lp.max_len &&
+                          q.lp.n_wg == lp.n_wg && q.lp.row_slots == lp.row_slots;
+        if (same) C.entries.erase(C.entries.begin() + i); else i++;
+    }
+    C.entries.push_back({side, lp, std::move(L)});
+    while (!X->M.shell && (int)C.entries.size() > cap) {          // (a shell cannot cut an evicted layout again: it keeps them all)
+        const Layout *gone = C.entries.front().layout.get();
+        C.entries.erase(C.entries.begin());
+        for (size_t i = 0; i < C.copies.size();)
+            if (C.copies[i].key == gone) C.copies.erase(C.copies.begin() + i); else i++;
+    }
+}
+
+std::vector<int32_t> rank_classes(const int32_t *ranks, int32_t count, int32_t max_classes)
+{
+    std::vector<int32_t> padded;
+    for (int32_t q = 0; q < count; q++) padded.push_back(padded_rank(ranks[q]));
+    std::sort(padded.begin(), padded.end());
+    padded.erase(std::unique(padded.begin(), padded.end()), padded.end());
+    std::vector<int32_t> classes;
+    if (!padded.empty()) {
+        if (max_classes < 1) max_classes = 1;
+        int32_t top = padded.back();
+        classes.push_back(top);
+        while ((int32_t)classes.size() < max_classes) {
+            // the largest planned rank whose rows are at most half as wide as the current lowest class's
+            int32_t next = 0;
+            for (int32_t p : padded) if (lds_row_bytes(p) * 2 <= lds_row_bytes(top)) next = p;
+            if (!next) break;
+            classes.push_back(next);
+            top = next;
+        }
+        std::sort(classes.begin(), classes.end());
+    }
+    return classes;
 }
 
 int plan_class(const vbnmf_matrix *X, int R)
@@ -1031,6 +1102,7 @@ int vbnmf_matrix_info(const vbnmf_matrix *X, int64_t *n, int64_t *m, int64_t *nn
 int vbnmf_matrix_empty_counts(const vbnmf_matrix *X, int64_t *empty_rows, int64_t *empty_cols)
 {
     if (!X) return fail(VBNMF_ERR_BAD_ARG, "matrix handle is NULL");
+    if (X->M.shell) return fail(VBNMF_ERR_STATE, "this matrix handle is a shell (vbnmf_matrix_shell): it holds no entries");
     const Matrix &M = X->M;
     // rowSums(mat)==0 / colSums(mat)==0 of reference R/bayesian.R:244-245 (sums, not stored-entry counts).  Columns are
     // cut in chunks with their own row-sum arrays, added in chunk order (a fixed order: the test for == 0 must not
@@ -1071,28 +1143,9 @@ int vbnmf_matrix_empty_counts(const vbnmf_matrix *X, int64_t *empty_rows, int64_
 int vbnmf_matrix_plan_ranks(vbnmf_matrix *X, const int32_t *ranks, int32_t count, int32_t max_classes)
 {
     if (!X || (count > 0 && !ranks) || count < 0) return fail(VBNMF_ERR_BAD_ARG, "NULL argument");
-    std::vector<int32_t> padded;
-    for (int32_t q = 0; q < count; q++) {
+    for (int32_t q = 0; q < count; q++)
         if (ranks[q] < 1 || ranks[q] > VBNMF_MAX_RANK) return fail(VBNMF_ERR_BAD_ARG, "rank %d is outside [1, %d]", ranks[q], VBNMF_MAX_RANK);
-        padded.push_back(padded_rank(ranks[q]));
-    }
-    std::sort(padded.begin(), padded.end());
-    padded.erase(std::unique(padded.begin(), padded.end()), padded.end());
-    std::vector<int32_t> classes;
-    if (!padded.empty()) {
-        if (max_classes < 1) max_classes = 1;
-        int32_t top = padded.back();
-        classes.push_back(top);
-        while ((int32_t)classes.size() < max_classes) {
-            // the largest planned rank whose rows are at most half as wide as the current lowest class's
-            int32_t next = 0;
-            for (int32_t p : padded) if (lds_row_bytes(p) * 2 <= lds_row_bytes(top)) next = p;
-            if (!next) break;
-            classes.push_back(next);
-            top = next;
-        }
-        std::sort(classes.begin(), classes.end());
-    }
+    std::vector<int32_t> classes = rank_classes(ranks, count, max_classes);
     std::lock_guard<std::mutex> g(X->plan_mu);
     X->plan.swap(classes);
     return VBNMF_OK;
@@ -1106,6 +1159,7 @@ int vbnmf_layout_build(const vbnmf_matrix *X, int64_t col_begin, int64_t col_end
     if (!X || !out || !view) return fail(VBNMF_ERR_BAD_ARG, "NULL argument");
     if (side != 0 && side != 1) return fail(VBNMF_ERR_BAD_ARG, "side must be 0 or 1");
     if (r < 1 || r > VBNMF_MAX_RANK) return fail(VBNMF_ERR_BAD_ARG, "rank %d is outside [1, %d]", r, VBNMF_MAX_RANK);
+    if (X->M.shell) return fail(VBNMF_ERR_STATE, "this matrix handle is a shell (vbnmf_matrix_shell): it holds no entries");
     *out = nullptr;
     vbnmf_layout *H = nullptr;
     try {
@@ -1115,7 +1169,11 @@ int vbnmf_layout_build(const vbnmf_matrix *X, int64_t col_begin, int64_t col_end
         int64_t nmin = side == 0 ? col_end - col_begin : X->M.n;
         const bool range_ok = col_begin >= 0 && col_end <= X->M.m && col_begin < col_end;      // build_layout reports a bad range
         LayoutParams lp = default_layout_params(nmaj, nmin, R, 0, range_ok ? X->M.colptr[col_end] - X->M.colptr[col_begin] : 0);
-        int rc = build_layout(X->M, col_begin, col_end, side, lp, H->L);
+        // the cells in the order an engine on these columns uses (order.cpp): the matrix's for the whole matrix, the range's own otherwise
+        std::vector<int32_t> own;
+        const bool whole = col_begin == 0 && col_end == X->M.m;
+        if (!whole && range_ok) own = compute_cell_order(X->M, col_begin, col_end);
+        int rc = build_layout(X->M, col_begin, col_end, side, lp, whole ? &X->M.cell_order() : &own, H->L);
         if (rc) { delete H; return rc; }
     } catch (const std::bad_alloc &) {
         delete H;
@@ -1134,10 +1192,240 @@ int vbnmf_layout_build(const vbnmf_matrix *X, int64_t col_begin, int64_t col_end
     view->packed = L.wide ? nullptr : L.packed.data();
     view->wide_idx = L.wide ? L.wide_idx.data() : nullptr;
     view->wide_val = L.wide ? L.wide_val.data() : nullptr;
+    view->cell_perm = L.cell_perm.empty() ? nullptr : L.cell_perm.data();
     *out = H;
     return VBNMF_OK;
 }
 
 void vbnmf_layout_destroy(vbnmf_layout *L) { delete L; }
+
+}  // extern "C"
+
+// ---------------------------------------------------------------- node-shared layouts (one build per node, not per process)
+//
+// The reference ships the whole `bundle` -- the matrix included -- to every MPI slave (reference R/bayesian.R:252-263) and
+// every slave densifies it again per iteration.  Here the processes of one node (one per GPU) share ONE ingestion and
+// ONE pair of tiled layouts: the process that holds X exports a layout as a flat blob (into shared memory the caller
+// maps), the others import it into a matrix SHELL -- a handle with X's metadata and no entries -- and upload it to their
+// own GPU.  Blob = header (int64 words) + the layout's arrays, each 64-byte aligned, + a closing magic word.
+namespace {
+
+constexpr int64_t kBlobMagic = 0x56424E4D464C5930LL;      // "VBNMFLY0"
+constexpr int64_t kBlobVersion = 2;
+constexpr int kBlobHeaderWords = 48;
+constexpr int kBlobArrays = 15;
+
+struct BlobArray { const void *src; void *dst; int64_t bytes; };
+
+inline int64_t align64(int64_t v) { return (v + 63) & ~(int64_t)63; }
+
+template <class V> int64_t vec_bytes(const V &v) { return (int64_t)v.size() * (int64_t)sizeof(typename V::value_type); }
+
+// the arrays of a layout in blob order (pointers valid while L is)
+void blob_arrays(const Layout &L, BlobArray (&a)[kBlobArrays])
+{
+    int q = 0;
+    auto put = [&](const auto &v) { a[q].src = v.data(); a[q].dst = nullptr; a[q].bytes = vec_bytes(v); q++; };
+    put(L.task_major); put(L.slice_width); put(L.slice_off); put(L.slice_block); put(L.slice_fast); put(L.block_start);
+    put(L.seg_block); put(L.wg_seg0); put(L.seg_ptr); put(L.inv_ptr); put(L.inv_task); put(L.packed); put(L.wide_idx); put(L.wide_val);
+    put(L.cell_perm);
+}
+
+void parallel_copy(void *dst, const void *src, int64_t bytes)
+{
+    const int64_t chunk = (int64_t)4 << 20;
+    const int64_t nchunks = (bytes + chunk - 1) / chunk;
+    parallel_for(nchunks, [&](int64_t b, int64_t e, int) {
+        for (int64_t c = b; c < e; c++) {
+            const int64_t o = c * chunk, len = std::min(chunk, bytes - o);
+            std::memcpy(static_cast<char *>(dst) + o, static_cast<const char *>(src) + o, (size_t)len);
+        }
+    });
+}
+
+// geometry of the whole-matrix layout of `side` that an engine of rank `geometry_rank` with n_wg workgroups uses
+LayoutParams whole_matrix_params(const vbnmf_matrix *X, int side, int geometry_rank, int n_wg)
+{
+    const int R = padded_rank(geometry_rank);
+    const int64_t nmaj = side == 0 ? X->M.n : X->M.m, nmin = side == 0 ? X->M.m : X->M.n;
+    return default_layout_params(nmaj, nmin, R, n_wg, X->M.nnz);
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t vbnmf_padded_rank(int32_t r) { return (r < 1 || r > VBNMF_MAX_RANK) ? 0 : padded_rank(r); }
+
+// Rank classes of a sweep (see vbnmf_matrix_plan_ranks) WITHOUT touching a matrix: classes[0..n) = padded ranks, ascending.
+int vbnmf_plan_classes(const int32_t *ranks, int32_t count, int32_t max_classes, int32_t *classes, int32_t *n_classes)
+{
+    if ((count > 0 && !ranks) || count < 0 || !classes || !n_classes) return fail(VBNMF_ERR_BAD_ARG, "NULL argument");
+    for (int32_t q = 0; q < count; q++)
+        if (ranks[q] < 1 || ranks[q] > VBNMF_MAX_RANK) return fail(VBNMF_ERR_BAD_ARG, "rank %d is outside [1, %d]", ranks[q], VBNMF_MAX_RANK);
+    const std::vector<int32_t> c = rank_classes(ranks, count, max_classes);
+    for (size_t q = 0; q < c.size(); q++) classes[q] = c[q];       // at most `count` entries
+    *n_classes = (int32_t)c.size();
+    return VBNMF_OK;
+}
+
+// meta[8] = n, m, stored entries, counts_int, counts_u16, max value, sum lgamma(x+1), sum(-x log x + x)
+int vbnmf_matrix_get_meta(const vbnmf_matrix *X, double *meta)
+{
+    if (!X || !meta) return fail(VBNMF_ERR_BAD_ARG, "NULL argument");
+    if (!X->M.shell) std::call_once(X->xlx_once, [&] { X->xlx = sum_xlogx(X->M, 0, X->M.m); });
+    meta[0] = (double)X->M.n; meta[1] = (double)X->M.m; meta[2] = (double)X->M.nnz;
+    meta[3] = X->M.counts_int ? 1.0 : 0.0; meta[4] = X->M.counts_u16 ? 1.0 : 0.0; meta[5] = X->M.max_val;
+    meta[6] = X->lgx; meta[7] = X->xlx;
+    return VBNMF_OK;
+}
+
+int vbnmf_matrix_shell(const double *meta, vbnmf_matrix **out)
+{
+    if (!meta || !out) return fail(VBNMF_ERR_BAD_ARG, "NULL argument");
+    *out = nullptr;
+    const int64_t n = (int64_t)meta[0], m = (int64_t)meta[1], nnz = (int64_t)meta[2];
+    if (int rc = check_dims(n, m)) return rc;
+    if (nnz < 0) return fail(VBNMF_ERR_BAD_ARG, "negative entry count");
+    vbnmf_matrix *X = new (std::nothrow) vbnmf_matrix();
+    if (!X) return fail(VBNMF_ERR_OOM, "out of host memory");
+    X->M.shell = true;
+    X->M.n = n; X->M.m = m; X->M.nnz = nnz;
+    X->M.counts_int = meta[3] != 0.0; X->M.counts_u16 = meta[4] != 0.0; X->M.max_val = meta[5];
+    X->lgx = meta[6];
+    std::call_once(X->xlx_once, [&] { X->xlx = meta[7]; });
+    *out = X;
+    return VBNMF_OK;
+}
+
+int vbnmf_matrix_is_shell(const vbnmf_matrix *X) { return X && X->M.shell ? 1 : 0; }
+
+// Blob of the whole-matrix layout of `side` in the geometry of rank `geometry_rank` for engines with n_wg sweep
+// workgroups (vbnmf_device_sweep_workgroups).  buf == NULL: builds (and caches) the layout and returns its blob size in
+// *bytes; otherwise writes the blob (all host threads) into buf[0..capacity).
+int vbnmf_matrix_export_layout(const vbnmf_matrix *X, int32_t side, int32_t geometry_rank, int32_t n_wg, void *buf,
+                               int64_t capacity, int64_t *bytes)
+{
+    if (!X || !bytes) return fail(VBNMF_ERR_BAD_ARG, "NULL argument");
+    if (side != 0 && side != 1) return fail(VBNMF_ERR_BAD_ARG, "side must be 0 or 1");
+    if (geometry_rank < 1 || geometry_rank > VBNMF_MAX_RANK) return fail(VBNMF_ERR_BAD_ARG, "rank %d is outside [1, %d]", geometry_rank, VBNMF_MAX_RANK);
+    if (n_wg < 1) return fail(VBNMF_ERR_BAD_ARG, "n_wg must be positive");
+    std::shared_ptr<const Layout> L;
+    LayoutParams lp;
+    try {
+        lp = whole_matrix_params(X, side, geometry_rank, n_wg);
+        int rc = VBNMF_OK;
+        L = shared_layout(X, side, lp, rc);
+        if (rc) return rc;
+    } catch (const std::bad_alloc &) {
+        return fail(VBNMF_ERR_OOM, "out of host memory building the layout");
+    }
+    BlobArray a[kBlobArrays];
+    blob_arrays(*L, a);
+    int64_t total = kBlobHeaderWords * 8;
+    for (int q = 0; q < kBlobArrays; q++) total = align64(total) + a[q].bytes;
+    total = align64(total) + 8;
+    *bytes = total;
+    if (!buf) return VBNMF_OK;
+    if (capacity < total) return fail(VBNMF_ERR_BAD_ARG, "the buffer holds %lld bytes, the layout blob needs %lld", (long long)capacity, (long long)total);
+    int64_t *h = static_cast<int64_t *>(buf);
+    std::memset(h, 0, kBlobHeaderWords * 8);
+    h[0] = kBlobMagic; h[1] = kBlobVersion; h[2] = total;
+    h[3] = L->side; h[4] = L->wide ? 1 : 0; h[5] = L->n_major; h[6] = L->n_minor; h[7] = L->block_width; h[8] = L->n_blocks;
+    h[9] = L->max_len; h[10] = L->n_wg; h[11] = L->row_slots; h[12] = L->n_tasks; h[13] = L->n_slices; h[14] = L->n_slots;
+    h[15] = L->n_segs; h[16] = L->nnz;
+    h[17] = lp.block_width; h[18] = lp.block_cap; h[19] = lp.max_len; h[20] = lp.n_wg; h[21] = lp.row_slots;
+    h[22] = X->M.n; h[23] = X->M.m; h[24] = X->M.nnz;
+    for (int q = 0; q < kBlobArrays; q++) h[32 + q] = a[q].bytes;
+    int64_t off = kBlobHeaderWords * 8;
+    for (int q = 0; q < kBlobArrays; q++) {
+        off = align64(off);
+        parallel_copy(static_cast<char *>(buf) + off, a[q].src, a[q].bytes);
+        off += a[q].bytes;
+    }
+    off = align64(off);
+    std::memcpy(static_cast<char *>(buf) + off, &kBlobMagic, 8);
+    return VBNMF_OK;
+}
+
+// Adds the layout in buf[0..bytes) (written by vbnmf_matrix_export_layout, this library version) to X's cache: engines
+// created afterwards in that geometry use it instead of cutting their own.  X: a shell or a full handle of the same matrix.
+int vbnmf_matrix_import_layout(const vbnmf_matrix *X, const void *buf, int64_t bytes)
+{
+    if (!X || !buf) return fail(VBNMF_ERR_BAD_ARG, "NULL argument");
+    if (bytes < kBlobHeaderWords * 8 + 8) return fail(VBNMF_ERR_BAD_ARG, "layout blob is truncated (%lld bytes)", (long long)bytes);
+    const int64_t *h = static_cast<const int64_t *>(buf);
+    if (h[0] != kBlobMagic || h[1] != kBlobVersion) return fail(VBNMF_ERR_BAD_ARG, "not a layout blob of this library version");
+    if (h[2] != bytes) return fail(VBNMF_ERR_BAD_ARG, "layout blob says %lld bytes, %lld were handed in", (long long)h[2], (long long)bytes);
+    if (h[22] != X->M.n || h[23] != X->M.m || h[24] != X->M.nnz)
+        return fail(VBNMF_ERR_BAD_ARG, "the layout blob was cut from a %lld x %lld matrix with %lld entries, this handle is %lld x %lld with %lld",
+                    (long long)h[22], (long long)h[23], (long long)h[24], (long long)X->M.n, (long long)X->M.m, (long long)X->M.nnz);
+    if (h[3] != 0 && h[3] != 1) return fail(VBNMF_ERR_BAD_ARG, "layout blob: bad side");
+    int64_t off = kBlobHeaderWords * 8;
+    for (int q = 0; q < kBlobArrays; q++) {
+        if (h[32 + q] < 0) return fail(VBNMF_ERR_BAD_ARG, "layout blob: negative array size");
+        off = align64(off) + h[32 + q];
+        if (off > bytes) return fail(VBNMF_ERR_BAD_ARG, "layout blob: arrays run past the end");
+    }
+    off = align64(off);
+    int64_t tail = 0;
+    if (off + 8 != bytes) return fail(VBNMF_ERR_BAD_ARG, "layout blob: size does not match its array table");
+    std::memcpy(&tail, static_cast<const char *>(buf) + off, 8);
+    if (tail != kBlobMagic) return fail(VBNMF_ERR_BAD_ARG, "layout blob: closing word missing (a partial write?)");
+    try {
+        auto L = std::make_shared<Layout>();
+        L->side = (int)h[3]; L->wide = h[4] != 0; L->n_major = h[5]; L->n_minor = h[6]; L->block_width = (int32_t)h[7];
+        L->n_blocks = (int32_t)h[8]; L->max_len = (int32_t)h[9]; L->n_wg = (int32_t)h[10]; L->row_slots = (int32_t)h[11];
+        L->n_tasks = h[12]; L->n_slices = h[13]; L->n_slots = h[14]; L->n_segs = h[15]; L->nnz = h[16];
+        LayoutParams lp;
+        lp.block_width = (int32_t)h[17]; lp.block_cap = (int32_t)h[18]; lp.max_len = (int32_t)h[19]; lp.n_wg = (int32_t)h[20]; lp.row_slots = (int32_t)h[21];
+        int q = 0;
+        int64_t o = kBlobHeaderWords * 8;
+        int rc = VBNMF_OK;
+        auto take = [&](auto &v) {
+            using T = typename std::remove_reference<decltype(v)>::type::value_type;
+            o = align64(o);
+            const int64_t nb = h[32 + q];
+            if (nb % (int64_t)sizeof(T)) rc = fail(VBNMF_ERR_BAD_ARG, "layout blob: array %d has a ragged size", q);
+            else {
+                v.resize((size_t)(nb / (int64_t)sizeof(T)));
+                parallel_copy(v.data(), static_cast<const char *>(buf) + o, nb);
+            }
+            o += nb; q++;
+        };
+        take(L->task_major); take(L->slice_width); take(L->slice_off); take(L->slice_block); take(L->slice_fast); take(L->block_start);
+        take(L->seg_block); take(L->wg_seg0); take(L->seg_ptr); take(L->inv_ptr); take(L->inv_task); take(L->packed); take(L->wide_idx); take(L->wide_val);
+        take(L->cell_perm);
+        if (rc) return rc;
+        // the renumbering of the cells: a permutation, and the SAME one for every layout of this matrix (the engine's
+        // cell-indexed arrays live in it); a shell adopts the first one it sees
+        if (!L->cell_perm.empty()) {
+            if ((int64_t)L->cell_perm.size() != X->M.m) return fail(VBNMF_ERR_BAD_ARG, "layout blob: cell order of the wrong length");
+            std::vector<char> seen(X->M.m, 0);
+            for (int32_t v : L->cell_perm) {
+                if (v < 0 || v >= X->M.m || seen[v]) return fail(VBNMF_ERR_BAD_ARG, "layout blob: the cell order is not a permutation");
+                seen[v] = 1;
+            }
+        }
+        std::call_once(X->M.order_cache->once, [&] { X->M.order_cache->perm = L->cell_perm; });
+        if (X->M.order_cache->perm != L->cell_perm)
+            return fail(VBNMF_ERR_BAD_ARG, "layout blob: its cell order differs from the one this matrix handle already uses");
+        // the scalar fields must agree with the arrays they describe (the kernels index by them)
+        const bool ok = (int64_t)L->task_major.size() == L->n_slices * kLanes && (int64_t)L->slice_width.size() == L->n_slices &&
+                        (int64_t)L->slice_off.size() == L->n_slices && (int64_t)L->slice_fast.size() == L->n_slices &&
+                        (int64_t)L->block_start.size() == (int64_t)L->n_blocks + 1 && (int64_t)L->seg_block.size() == L->n_segs &&
+                        (int64_t)L->wg_seg0.size() == (int64_t)L->n_wg + 1 && (int64_t)L->seg_ptr.size() == L->n_segs + 1 &&
+                        (int64_t)L->inv_ptr.size() == L->n_major + 1 && (int64_t)L->inv_task.size() == L->n_tasks &&
+                        (L->wide ? ((int64_t)L->wide_idx.size() == L->n_slots && (int64_t)L->wide_val.size() == L->n_slots)
+                                 : (int64_t)L->packed.size() == L->n_slots) &&
+                        L->n_major == (L->side == 0 ? X->M.n : X->M.m) && L->n_minor == (L->side == 0 ? X->M.m : X->M.n) &&
+                        L->wide == !X->M.counts_int;
+        if (!ok) return fail(VBNMF_ERR_BAD_ARG, "layout blob: header and arrays disagree");
+        cache_layout(X, L->side, lp, L);
+    } catch (const std::bad_alloc &) {
+        return fail(VBNMF_ERR_OOM, "out of host memory importing the layout");
+    }
+    return VBNMF_OK;
+}
 
 }  // extern "C"

@@ -77,14 +77,16 @@ __device__ inline double gamma_draw(double a, double scale, uint64_t element, ui
 // index is the GLOBAL (major, k) position (major0 = first cell of a partition), so a partitioned run draws the same H.
 __global__ __launch_bounds__(256) void k_gamma_init(double *__restrict__ f, double *__restrict__ e, double *__restrict__ dvar,
                                                     int64_t nmaj, int64_t major0, int r, int R, double a, double b,
-                                                    uint32_t factor, uint32_t k0, uint32_t k1)
+                                                    uint32_t factor, uint32_t k0, uint32_t k1, const int32_t *__restrict__ perm)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= nmaj * R) return;
     const int64_t M = i / R;
     const int k = (int)(i - M * R);
     double v = 0.0;
-    if (k < r) v = gamma_draw(a, b / a, (uint64_t)(major0 + M) * (uint64_t)r + (uint64_t)k, factor, k0, k1);
+    // (perm: the layout's order of the cells -- row M of the array is the caller's major perm[M]; the draw is keyed by the
+    // CALLER's global element index, so it does not depend on the order, the launch geometry or the partitioning)
+    if (k < r) v = gamma_draw(a, b / a, (uint64_t)(major0 + (perm ? (int64_t)perm[M] : M)) * (uint64_t)r + (uint64_t)k, factor, k0, k1);
     f[i] = v;
     if (e) e[i] = v;
     if (dvar) dvar[i] = 0.0;

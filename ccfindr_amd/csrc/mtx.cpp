@@ -274,12 +274,14 @@ int vbnmf_matrix_from_mtx(const char *path, vbnmf_matrix **out)
 int vbnmf_matrix_write_mtx(const vbnmf_matrix *X, const char *path)
 {
     if (!X || !path) return fail(VBNMF_ERR_BAD_ARG, "NULL argument");
+    if (X->M.shell) return fail(VBNMF_ERR_STATE, "this matrix handle is a shell (vbnmf_matrix_shell): it holds no entries");
     return matrix_write_mtx(X->M, path);
 }
 
 int vbnmf_matrix_csc(const vbnmf_matrix *X, const int64_t **colptr, const int32_t **row, const double **val)
 {
     if (!X) return fail(VBNMF_ERR_BAD_ARG, "matrix handle is NULL");
+    if (X->M.shell) return fail(VBNMF_ERR_STATE, "this matrix handle is a shell (vbnmf_matrix_shell): it holds no entries");
     if (colptr) *colptr = X->M.colptr.data();
     if (row) *row = X->M.row.data();
     if (val) *val = X->M.val.data();

@@ -112,6 +112,55 @@ class CountMatrix:
         N.check(self._lib.vbnmf_matrix_empty_counts(self._h, ctypes.byref(er), ctypes.byref(ec)))
         return er.value, ec.value
 
+    # -- one ingestion / one pair of layouts per node (vbnmf_matrix_get_meta / _shell / _export_layout / _import_layout) ----
+    def meta(self):
+        """The eight numbers a shell of this matrix needs (dimensions, entry count, value-kind flags, constants)."""
+        out = np.empty(8)
+        N.check(self._lib.vbnmf_matrix_get_meta(self._h, N.dptr(out)))
+        return out
+
+    @classmethod
+    def shell(cls, meta):
+        """A handle with X's metadata and NO entries: engines on it use layouts imported from the process that holds X
+        (``import_layout``); anything that needs the entries raises ``VBNMFError`` (status 5)."""
+        self = cls.__new__(cls)
+        L = N.load()
+        self._lib = L
+        self._h = ctypes.c_void_p()
+        meta = np.ascontiguousarray(meta, dtype=np.float64)
+        N.check(L.vbnmf_matrix_shell(N.dptr(meta), ctypes.byref(self._h)))
+        self.shape = (int(meta[0]), int(meta[1]))
+        self.nnz = int(meta[2])
+        self.sum_lgamma_x1 = float(meta[6])
+        return self
+
+    @property
+    def is_shell(self):
+        return bool(self._lib.vbnmf_matrix_is_shell(self._h))
+
+    def layout_blob_size(self, side, geometry_rank, n_wg):
+        """Cuts (and caches) the whole-matrix layout of ``side`` in the geometry of ``geometry_rank`` -> blob bytes."""
+        nb = ctypes.c_int64()
+        N.check(self._lib.vbnmf_matrix_export_layout(self._h, int(side), int(geometry_rank), int(n_wg), None, 0, ctypes.byref(nb)))
+        return nb.value
+
+    def export_layout(self, side, geometry_rank, n_wg, buf):
+        """Writes that layout's blob into ``buf`` (a writable buffer, e.g. a shared-memory mapping) -> bytes written."""
+        view = (ctypes.c_char * len(buf)).from_buffer(buf)
+        nb = ctypes.c_int64()
+        N.check(self._lib.vbnmf_matrix_export_layout(self._h, int(side), int(geometry_rank), int(n_wg),
+                                                     ctypes.cast(view, ctypes.c_void_p), len(buf), ctypes.byref(nb)))
+        return nb.value
+
+    def import_layout(self, buf, nbytes=None):
+        """Adds the layout blob in ``buf`` (written by ``export_layout`` in another process of the node) to this handle."""
+        nbytes = len(buf) if nbytes is None else int(nbytes)
+        try:
+            view = (ctypes.c_char * len(buf)).from_buffer(buf)
+        except TypeError:                                           # a read-only mapping / bytes
+            view = (ctypes.c_char * len(buf)).from_buffer_copy(buf)
+        N.check(self._lib.vbnmf_matrix_import_layout(self._h, ctypes.cast(view, ctypes.c_void_p), nbytes))
+
     def plan_ranks(self, ranks=(), max_classes=1):
         """Rank classes for a sweep over several ranks (vbnmf_matrix_plan_ranks): engines created afterwards share the
         tiled layouts of the smallest class at or above their rank instead of cutting a pair per LDS row size.  An empty
@@ -131,6 +180,34 @@ class CountMatrix:
             pass
 
 
+def rank_classes(ranks, max_classes=1):
+    """Rank classes of a sweep (vbnmf_plan_classes): padded ranks, ascending; an engine of rank r takes the geometry of
+    the smallest class at or above ``padded_rank(r)``."""
+    L = N.load()
+    arr = np.asarray(sorted({int(r) for r in ranks}), dtype=np.int32)
+    out = np.zeros(max(arr.size, 1), dtype=np.int32)
+    cnt = ctypes.c_int32()
+    N.check(L.vbnmf_plan_classes(arr.ctypes.data_as(N.c_int32_p), int(arr.size), int(max_classes), out.ctypes.data_as(N.c_int32_p),
+                                 ctypes.byref(cnt)))
+    return [int(v) for v in out[:cnt.value]]
+
+
+def geometry_rank_for(rank, classes):
+    """The class (a padded rank) an engine of ``rank`` uses, 0 when no class covers it (its own geometry)."""
+    pr = int(N.load().vbnmf_padded_rank(int(rank)))
+    for c in classes or ():
+        if c >= pr:
+            return int(c)
+    return 0
+
+
+def sweep_workgroups(device=0):
+    """Persistent workgroups of the sweep kernels on ``device``: the ``n_wg`` of its whole-matrix layouts."""
+    v = ctypes.c_int32()
+    N.check(N.load().vbnmf_device_sweep_workgroups(int(device), ctypes.byref(v)))
+    return v.value
+
+
 class _CudaBuffer:
     """Exposes a raw device pointer through __cuda_array_interface__ (for torch.as_tensor)."""
 
@@ -141,17 +218,17 @@ class _CudaBuffer:
 class VBEngine:
     """Device-resident state of one factorisation (one rank, one column block of X)."""
 
-    def __init__(self, X: CountMatrix, rank: int, device: int = 0, cols=None, m_global=None):
+    def __init__(self, X: CountMatrix, rank: int, device: int = 0, cols=None, m_global=None, geometry_rank: int = 0):
+        """``geometry_rank`` (>= rank): the rank whose LDS row size the tiled layouts are cut for -- the ranks of a sweep
+        share one pair of layouts (``rank_classes``); 0: the matrix's plan (``CountMatrix.plan_ranks``) or the rank's own."""
         L = N.load()
         self._lib = L
         self._h = ctypes.c_void_p()
         self.X = X
-        if cols is None:
-            N.check(L.vbnmf_engine_create(X._h, int(rank), int(device), ctypes.byref(self._h)))
-        else:
-            cb, ce = cols
-            mg = X.shape[1] if m_global is None else m_global
-            N.check(L.vbnmf_engine_create_part(X._h, int(cb), int(ce), int(mg), int(rank), int(device), ctypes.byref(self._h)))
+        cb, ce = (0, X.shape[1]) if cols is None else cols
+        mg = X.shape[1] if m_global is None else m_global
+        N.check(L.vbnmf_engine_create_geom(X._h, int(cb), int(ce), int(mg), int(rank), int(geometry_rank), int(device),
+                                           ctypes.byref(self._h)))
         n, m, r = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int32()
         N.check(L.vbnmf_engine_dims(self._h, ctypes.byref(n), ctypes.byref(m), ctypes.byref(r)))
         self.n, self.m, self.rank = n.value, m.value, r.value
@@ -167,15 +244,26 @@ class VBEngine:
     def state_finish(self):
         N.check(self._lib.vbnmf_engine_state_finish(self._h))
 
-    def get_state(self, names=("lw", "lh", "ew", "eh", "dw", "dh")):
-        out = {}
-        for k in ("lw", "ew", "dw"):
-            out[k] = np.empty((self.n, self.rank), order="F") if k in names else None
-        for k in ("lh", "eh", "dh"):
-            out[k] = np.empty((self.rank, self.m), order="F") if k in names else None
-        N.check(self._lib.vbnmf_engine_get_state(self._h, N.dptr(out["lw"]), N.dptr(out["lh"]), N.dptr(out["ew"]),
-                                                 N.dptr(out["eh"]), N.dptr(out["dw"]), N.dptr(out["dh"])))
-        return {k: v for k, v in out.items() if v is not None}
+    supports_state_out = True
+
+    def get_state(self, names=("lw", "lh", "ew", "eh", "dw", "dh"), out=None):
+        """The named members of ``wh`` as column-major arrays.  ``out``: a mapping name -> preallocated column-major fp64
+        array of the member's shape (e.g. views into shared memory): the library writes straight into it."""
+        res = {}
+        for k in ("lw", "ew", "dw", "lh", "eh", "dh"):
+            shape = (self.n, self.rank) if k in ("lw", "ew", "dw") else (self.rank, self.m)
+            if k not in names:
+                res[k] = None
+            elif out is not None and k in out:
+                a = out[k]
+                if a.shape != shape or a.dtype != np.float64 or not a.flags.f_contiguous or not a.flags.writeable:
+                    raise ValueError(f"out['{k}'] must be a writable column-major float64 array of shape {shape}")
+                res[k] = a
+            else:
+                res[k] = np.empty(shape, order="F")
+        N.check(self._lib.vbnmf_engine_get_state(self._h, N.dptr(res["lw"]), N.dptr(res["lh"]), N.dptr(res["ew"]),
+                                                 N.dptr(res["eh"]), N.dptr(res["dw"]), N.dptr(res["dh"])))
+        return {k: v for k, v in res.items() if v is not None}
 
     # -- stepping ------------------------------------------------------------------------
     def step(self, hyper, fudge=EPS):

@@ -1,0 +1,99 @@
+"""Host memory shared by the processes of ONE node (one process per GPU): segments under /dev/shm, mapped by name.
+
+Eight MI355X share one host.  What the host computes once -- the ingestion of X, the two tiled layouts of a rank sweep --
+or collects once -- the factor matrices of the sweep's units -- lives in a segment every process of the node maps,
+instead of being rebuilt by every process or pickled through a process-group gather.  The reference ships the whole
+``bundle`` to every MPI slave and gathers the per-run lists through Rmpi (reference R/bayesian.R:252-263); here the
+data plane between the processes of a node is the node's own memory.
+
+A segment is a file in /dev/shm created exclusively by its owner; peers open it by name (the name travels through the
+process group as a tiny host object); the owner unlinks it as soon as every peer holds its mapping, so nothing is left
+behind when a process dies afterwards.
+"""
+from __future__ import annotations
+
+import mmap
+import os
+import socket
+import uuid
+
+import numpy as np
+
+
+def shm_dir():
+    d = os.environ.get("VBNMF_SHM_DIR") or "/dev/shm"
+    if not os.path.isdir(d):
+        import tempfile
+        d = tempfile.gettempdir()
+    return d
+
+
+def node_key():
+    """What two processes must agree on to share /dev/shm: host name + the kernel's boot id.  ``VBNMF_NODE_KEY`` overrides
+    (tests use it to rehearse the several-nodes path on one machine)."""
+    forced = os.environ.get("VBNMF_NODE_KEY")
+    if forced:
+        return forced
+    try:
+        boot = open("/proc/sys/kernel/random/boot_id").read().strip()
+    except OSError:
+        boot = ""
+    return f"{socket.gethostname()}:{boot}:{shm_dir()}"
+
+
+def fresh_name(tag):
+    return f"vbnmf_{tag}_{os.getpid()}_{uuid.uuid4().hex[:12]}"
+
+
+class Segment:
+    """One shared mapping.  ``Segment.create(name, nbytes)`` (owner) / ``Segment.open(name)`` (peer)."""
+
+    def __init__(self, name, mapping, size, owner):
+        self.name, self.map, self.size, self.owner = name, mapping, size, owner
+        self._unlinked = False
+
+    @classmethod
+    def create(cls, name, nbytes):
+        path = os.path.join(shm_dir(), name)
+        fd = os.open(path, os.O_CREAT | os.O_EXCL | os.O_RDWR, 0o600)
+        try:
+            os.ftruncate(fd, max(int(nbytes), 1))             # sparse: pages appear as they are written
+            mapping = mmap.mmap(fd, max(int(nbytes), 1))
+        except BaseException:
+            os.close(fd)
+            os.unlink(path)
+            raise
+        os.close(fd)
+        return cls(name, mapping, max(int(nbytes), 1), True)
+
+    @classmethod
+    def open(cls, name):
+        path = os.path.join(shm_dir(), name)
+        fd = os.open(path, os.O_RDWR)
+        try:
+            size = os.fstat(fd).st_size
+            mapping = mmap.mmap(fd, size)
+        finally:
+            os.close(fd)
+        return cls(name, mapping, size, False)
+
+    def array(self, offset, shape, dtype=np.float64, order="F"):
+        """A numpy view into the segment (it keeps the mapping alive for as long as the array lives)."""
+        count = int(np.prod(shape))
+        a = np.frombuffer(self.map, dtype=dtype, count=count, offset=int(offset))
+        return a.reshape(shape, order=order)
+
+    def unlink(self):
+        if self.owner and not self._unlinked:
+            self._unlinked = True
+            try:
+                os.unlink(os.path.join(shm_dir(), self.name))
+            except FileNotFoundError:
+                pass
+
+    def close(self):
+        self.unlink()
+        try:
+            self.map.close()
+        except (BufferError, ValueError):                     # views are still alive: the mapping goes with the last of them
+            pass

@@ -50,17 +50,56 @@ def sweep_tasks(ranks, nrun):
     return tasks, [float(r) for _, r in tasks]
 
 
+# columns of the per-unit record that travels through the process group (one small fp64 tensor, summed)
+_REC_DONE, _REC_LK0, _REC_AW, _REC_BW, _REC_AH, _REC_BH, _REC_NSTEPS, _REC_FAIL, _REC_OWNER, _REC_UNIF0 = range(10)
+
+
+def _unit_offsets(tasks, n, m):
+    """Byte offsets of every unit's four factor matrices [ew | eh | sdw | sdh] in the node's result segment."""
+    off, table = 0, {}
+    for t, (_, r) in enumerate(tasks):
+        table[t] = off
+        off += 8 * 2 * (n * r + r * m)
+    return table, off
+
+
+def _unit_views(seg, base, n, m, r):
+    nr, rm = 8 * n * r, 8 * r * m
+    return {"ew": seg.array(base, (n, r)), "eh": seg.array(base + nr, (r, m)),
+            "dw": seg.array(base + nr + rm, (n, r)), "dh": seg.array(base + 2 * nr + rm, (r, m))}
+
+
 def vb_factorize_sharded(mat, ranks=2, nrun=1, verbose=0, initializer="random", Itmax=10000,
                          hyper_update=(True, True, True, True), gamma_a=1, gamma_b=1, Tol=1e-5,
                          hyper_update_n0=10, hyper_update_dn=1, fudge=None, unif_stop=True, seed=0,
-                         device=None, group=None, engine_factory=None, geometry_classes=1):
+                         device=None, group=None, engine_factory=None, geometry_classes=1, timings=None):
     """``vb_factorize`` with the (run, rank) units sharded over the ranks of a process group.
 
-    Call it from every process (``torch.distributed`` initialised, one process per GPU).
-    Every process returns the same ``VBResult``.  ``seed`` must be given (not None) so all
-    processes draw the same initial states.  Without a process group it runs everything locally.
+    Call it from every process (``torch.distributed`` initialised, one process per GPU).  Every process returns the
+    same ``VBResult``.  ``seed`` must be given (not None) so all processes draw the same initial states.  Without a
+    process group it runs everything locally.
+
+    What the node's host does ONCE, not once per process (the reference ships the whole bundle to every MPI slave and
+    gathers the per-run lists through Rmpi, reference R/bayesian.R:252-263):
+
+    * ``mat`` may be ``None`` on all processes of a node but one: the holder's ``CountMatrix`` is the only ingestion;
+      the others run their units on a *shell* (metadata, no entries);
+    * the tiled layouts of the sweep (one pair per rank class) are cut by the process(es) that hold X -- side by side
+      when several do -- written into /dev/shm and imported by everybody else (``ccfindr_amd.node``);
+    * a unit's factor matrices go from its engine straight into a shared result segment (``vbnmf_engine_get_state``
+      writes into the mapping); what travels through the process group is one small fp64 tensor -- evidence,
+      hyper-parameters, step counts, flags -- so every process assembles the same result from views into that segment.
+
+    Processes on other nodes (no shared /dev/shm) need their own holder of X; the factor matrices of units run on
+    another node arrive by tensor broadcast from their owner.  ``timings`` (a dict) receives this process's split of
+    the call: ``layout_s`` (cut / export / wait / import), ``units_s``, ``gather_s``.
     """
+    import time
+    import torch
     import torch.distributed as dist
+    from . import node as shm
+    from .engine import CountMatrix, geometry_rank_for, rank_classes, sweep_workgroups
+    t_begin = time.perf_counter()
     world, me = 1, 0
     if dist.is_available() and dist.is_initialized():
         world, me = dist.get_world_size(group), dist.get_rank(group)
@@ -68,49 +107,212 @@ def vb_factorize_sharded(mat, ranks=2, nrun=1, verbose=0, initializer="random", 
         raise ValueError("a sharded run needs an explicit seed")
     if device is None:
         device = me
-    bundle = make_bundle(mat, ranks, nrun, verbose, initializer, Itmax, hyper_update, gamma_a, gamma_b, Tol,
-                         hyper_update_n0, hyper_update_dn, fudge, unif_stop, seed, device, engine_factory)
+    native = engine_factory is None
+    X = None
+    if mat is not None:
+        X = mat if isinstance(mat, CountMatrix) or not native else CountMatrix(mat)
+    # ---- control plane, round 1 (tiny host objects): who holds X, on which node, and what the guards found
+    mine = {"node": shm.node_key(), "holds": X is not None, "meta": None, "empty": (0, 0), "n_wg": 0}
+    if X is not None and native:
+        mine["meta"] = [float(v) for v in X.meta()]
+        mine["empty"] = (0, 0) if X.is_shell else tuple(X.empty_counts())            # reference R/bayesian.R:244-247
+    elif X is not None:
+        mine["meta"] = [float(v) for v in (X.shape if hasattr(X, "shape") else np.asarray(X).shape)]
+    if native:
+        mine["n_wg"] = sweep_workgroups(device)         # (first HIP call of a fresh process: its runtime start-up runs while the holder cuts)
+    t_first = time.perf_counter()
+    peers = [mine]
+    if world > 1:
+        peers = [None] * world
+        dist.all_gather_object(peers, mine, group=group)
+    holders = [p for p in range(world) if peers[p]["holds"]]
+    if not holders:
+        raise ValueError("no process holds the count matrix (mat is None everywhere)")
+    for p in holders:                                    # the guards of vb_factorize, raised by EVERY process
+        if peers[p]["empty"][0] > 0:
+            raise ValueError("Input matrix contains empty rows")
+        if peers[p]["empty"][1] > 0:
+            raise ValueError("Input matrix contains empty columns")
+    my_node = [p for p in range(world) if peers[p]["node"] == mine["node"]]
+    node_holders = [p for p in my_node if peers[p]["holds"]]
+    if not node_holders:
+        raise ValueError(f"process {me}: no process of this node holds the count matrix; every node needs one holder")
+    meta = peers[node_holders[0]]["meta"]
+    if X is None and native:
+        X = CountMatrix.shell(meta)
+    n, m = int(meta[0]), int(meta[1])
+    bundle = make_bundle(X if native else mat, ranks, nrun, verbose, initializer, Itmax, hyper_update, gamma_a, gamma_b, Tol,
+                         hyper_update_n0, hyper_update_dn, fudge, unif_stop, seed, device, engine_factory) \
+        if (native or mat is not None) else None
+    if bundle is None:
+        raise ValueError("an injected engine_factory needs the matrix on every process")
     tasks, costs = sweep_tasks(bundle["ranks"], nrun)
-    mine = lpt_schedule(costs, world)[me]
+    schedule = lpt_schedule(costs, world)
+    owner_of = {t: p for p, ts in enumerate(schedule) for t in ts}
     bundle["engines"] = {} if nrun > 1 else None        # this process's restarts of a rank share the engine
-    # the geometry plan covers ALL ranks of the sweep, not only this process's units: every process cuts the same
-    # layouts, so a unit's result does not depend on which process ran it (bit for bit, as vb_factorize's)
-    planned = plan_geometry(bundle, geometry_classes)
-    # A unit that raises (hyper-parameter Newton failure, a VBNMFError, rank > min(nrow, ncol) ...) must not keep
-    # this process from the gather below: the other processes would wait in it for ever.  The error travels as a
-    # record, every process reaches the collective, and then every process raises the first error (by unit order).
+    if timings is not None:
+        bundle["unit_times"] = []
+    plan_geometry(bundle, geometry_classes)
+    segments = []                                        # everything this process created or mapped
+
+    # ---- the sweep's layouts: cut once per node, by its holders side by side, shared through /dev/shm
+    if native:
+        geoms = sorted({geometry_rank_for(r, bundle["classes"]) or int(r) for r in bundle["ranks"]})
+        pieces = [(g, side) for g in geoms for side in (0, 1)]
+        builder_of = {pc: node_holders[q % len(node_holders)] for q, pc in enumerate(pieces)}
+        n_wg = mine["n_wg"]
+        made = {}
+        detail = {} if timings is not None else None
+        tick = time.perf_counter
+        for pc in pieces:
+            if builder_of[pc] != me:
+                continue
+            if world == 1 or len(my_node) == 1:
+                continue                                 # nobody to share with: engine creation cuts (and caches) it
+            t0 = tick()
+            nb = X.layout_blob_size(pc[1], pc[0], n_wg)
+            t1 = tick()
+            seg = shm.Segment.create(shm.fresh_name(f"layout{pc[0]}_{pc[1]}"), nb)
+            segments.append(seg)
+            X.export_layout(pc[1], pc[0], n_wg, seg.map)
+            made[pc] = (seg.name, nb)
+            if detail is not None:
+                detail[f"cut_side{pc[1]}_s"] = t1 - t0
+                detail[f"export_side{pc[1]}_s"] = tick() - t1
+        if world > 1:
+            shared = [None] * world
+            t0 = tick()
+            dist.all_gather_object(shared, made, group=group)                    # control plane, round 2: segment names
+            if detail is not None:
+                detail["wait_for_builders_s"] = tick() - t0
+            t0 = tick()
+            for pc in pieces:
+                b = builder_of[pc]
+                if b == me or pc not in shared[b]:
+                    continue
+                if peers[b]["n_wg"] != n_wg:
+                    raise RuntimeError(f"process {b} cuts layouts for {peers[b]['n_wg']} workgroups, this device wants {n_wg}")
+                name, nb = shared[b][pc]
+                seg = shm.Segment.open(name)
+                X.import_layout(seg.map, nb)
+                seg.close()
+            if detail is not None:
+                detail["import_s"] = tick() - t0
+            t0 = tick()
+            dist.barrier(group=group)                    # every peer holds its copy: the owners unlink
+            if detail is not None:
+                detail["barrier_s"] = tick() - t0
+            for seg in segments:
+                seg.close()
+            segments = []
+    t_layout = time.perf_counter()
+
+    # ---- the result segment of this node: [ew | eh | sdw | sdh] of every unit, written by the unit's owner
+    offsets, total = _unit_offsets(tasks, n, m)
+    rseg = None
+    if world > 1 and len(my_node) > 1:
+        leader = my_node[0]
+        box = [None] * world
+        if me == leader:
+            rseg = shm.Segment.create(shm.fresh_name("results"), total)
+        dist.all_gather_object(box, rseg.name if me == leader else None, group=group)
+        if me != leader:
+            rseg = shm.Segment.open(box[leader])
+        dist.barrier(group=group)
+        rseg.unlink()                                    # mapped everywhere: the name can go, the memory lives with the mappings
+        bundle["state_out"] = lambda irun, r: _unit_views(rseg, offsets[tasks.index((irun, int(r)))], n, m, int(r))
+
+    # A unit that raises (hyper-parameter Newton failure, a VBNMFError, rank > min(nrow, ncol) ...) must not keep this
+    # process from the collectives below: the others would wait in them for ever.  The error travels as a flag, every
+    # process reaches the collectives, and then every process raises the first error (by unit order).
+    rmax = max([r for _, r in tasks] + [1])
+    rec = torch.zeros((len(tasks), _REC_UNIF0 + rmax), dtype=torch.float64)
     local, failure = {}, None
     try:
-        for t in mine:
+        for t in schedule[me]:
             try:
-                local[tasks[t]] = vb_run_rank(tasks[t][0], tasks[t][1], bundle)
-            except Exception as exc:                                 # noqa: BLE001 -- re-raised after the gather
+                out = vb_run_rank(tasks[t][0], tasks[t][1], bundle)
+                local[t] = out
+                row = rec[t]
+                row[_REC_DONE] = 1.0; row[_REC_LK0] = out["lk0"]; row[_REC_NSTEPS] = out["nsteps"]; row[_REC_OWNER] = me
+                for q, key in enumerate(("aw", "bw", "ah", "bh")):
+                    row[_REC_AW + q] = out["hyper"][key]
+                for c in out["unif"]:
+                    row[_REC_UNIF0 + c - 1] = 1.0
+            except Exception as exc:                                 # noqa: BLE001 -- re-raised after the exchange
                 failure = (t, me, type(exc).__name__, str(exc))
+                rec[t, _REC_FAIL] = 1.0
                 break
     finally:
         _close_engines(bundle)
-        if planned:
-            bundle["mat"].plan_ranks(())
+    t_units = time.perf_counter()
+
+    records = {}
     if world > 1:
-        gathered = [None] * world
-        dist.all_gather_object(gathered, (local, failure), group=group)   # control plane: host objects, once per sweep
-        records = {}
-        failures = []
-        for part, fail in gathered:
-            records.update(part)
-            if fail is not None:
-                failures.append(fail)
+        # one small tensor through the process group: every row is written by exactly one process, so the sum IS the gather
+        backend = dist.get_backend(group)
+        buf = rec.to(torch.device("cuda", device)) if backend == "nccl" else rec
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+        rec = buf.cpu()
+        if float(rec[:, _REC_FAIL].sum()) > 0:
+            fails = [None] * world
+            dist.all_gather_object(fails, failure, group=group)              # (rare path: the messages are host strings)
+            t, who, kind, msg = min(f for f in fails if f is not None)
+            irun, r = tasks[t]
+            raise ShardedRunError(f"unit (run {irun}, rank {r}) failed on process {who}: {kind}: {msg}")
+        for t, (irun, r) in enumerate(tasks):
+            row = rec[t]
+            if row[_REC_DONE] == 0:
+                continue
+            if t in local:
+                mats = local[t]
+            elif rseg is not None and owner_of[t] in my_node:
+                v = _unit_views(rseg, offsets[t], n, m, int(r))
+                mats = {"ew": v["ew"], "eh": v["eh"], "sdw": v["dw"], "sdh": v["dh"]}
+            else:
+                mats = None                                          # another node's unit: fetched below
+            records[(irun, r)] = {"rank": r, "lk0": float(row[_REC_LK0]), "nsteps": int(row[_REC_NSTEPS]),
+                                  "hyper": {k: float(row[_REC_AW + q]) for q, k in enumerate(("aw", "bw", "ah", "bh"))},
+                                  "unif": [c + 1 for c in range(int(r)) if row[_REC_UNIF0 + c] != 0], "_mats": mats}
+        # units of other nodes: their four matrices by tensor broadcast from the owner (no pickling)
+        remote = [t for t, (irun, r) in enumerate(tasks) if (irun, r) in records and
+                  any(peers[p]["node"] != peers[owner_of[t]]["node"] for p in range(world))]
+        for t in remote:
+            irun, r = tasks[t]
+            src = owner_of[t]
+            dev = torch.device("cuda", device) if backend == "nccl" else torch.device("cpu")
+            flat = torch.empty(2 * (n * r + r * m), dtype=torch.float64, device=dev)
+            if me == src:
+                o = local[t]
+                flat.copy_(torch.from_numpy(np.concatenate([np.asarray(o[k]).ravel(order="F") for k in ("ew", "eh", "sdw", "sdh")])))
+            dist.broadcast(flat, src=src if group is None else dist.get_global_rank(group, src), group=group)
+            if records[(irun, r)]["_mats"] is None:
+                a = flat.cpu().numpy()
+                nr, rm = n * r, r * m
+                records[(irun, r)]["_mats"] = {"ew": a[:nr].reshape((n, r), order="F"), "eh": a[nr:nr + rm].reshape((r, m), order="F"),
+                                               "sdw": a[nr + rm:2 * nr + rm].reshape((n, r), order="F"),
+                                               "sdh": a[2 * nr + rm:].reshape((r, m), order="F")}
+        for key, recd in records.items():
+            recd.update(recd.pop("_mats"))
     else:
-        records, failures = local, ([failure] if failure is not None else [])
-    if failures:
-        t, who, kind, msg = min(failures)
-        irun, r = tasks[t]
-        raise ShardedRunError(f"unit (run {irun}, rank {r}) failed on process {who}: {kind}: {msg}")
+        if failure is not None:
+            t, who, kind, msg = failure
+            irun, r = tasks[t]
+            raise ShardedRunError(f"unit (run {irun}, rank {r}) failed on process {who}: {kind}: {msg}")
+        records = {tasks[t]: out for t, out in local.items()}
     vb = []
     for irun in range(1, nrun + 1):
         per_rank = {r: records[(irun, r)] for r in bundle["ranks"] if (irun, r) in records}
         vb.append(assemble_run(per_rank, bundle["ranks"], unif_stop))
-    return select_best(vb, bundle["ranks"])
+    res = select_best(vb, bundle["ranks"])
+    if timings is not None:
+        t_end = time.perf_counter()
+        timings.update({"layout_s": t_layout - t_begin, "units_s": t_units - t_layout, "gather_s": t_end - t_units,
+                        "total_s": t_end - t_begin, "units": len(schedule[me]), "node_processes": len(my_node),
+                        "node_holders": len(node_holders), "is_shell": bool(native and X.is_shell),
+                        "layout_detail": (detail if native else None), "first_call_s": t_first - t_begin,
+                        "unit_detail": bundle.get("unit_times")})
+    return res
 
 
 # ---------------------------------------------------------------------------------------

@@ -102,7 +102,36 @@ int vbnmf_matrix_empty_counts(const vbnmf_matrix *X, int64_t *empty_rows, int64_
  * cutting one per row size.  Results do not depend on the plan beyond the summation order inside a step.
  * count = 0 clears the plan (every rank its own geometry, the default). */
 int vbnmf_matrix_plan_ranks(vbnmf_matrix *X, const int32_t *ranks, int32_t count, int32_t max_classes);
+/* The same classes without touching a matrix handle: classes[0..*n_classes) = padded ranks, ascending (at most `count`
+ * of them).  vb_factorize picks each engine's geometry from this list and hands it to vbnmf_engine_create_geom, so a
+ * sweep neither mutates the shared matrix handle nor loses a plan the caller set on it.  vbnmf_padded_rank: the rank as
+ * the device pads it (even up to 32, multiples of 8 up to 64, of 16 up to 128); 0 for a rank out of range. */
+int vbnmf_plan_classes(const int32_t *ranks, int32_t count, int32_t max_classes, int32_t *classes, int32_t *n_classes);
+int32_t vbnmf_padded_rank(int32_t r);
 void vbnmf_matrix_destroy(vbnmf_matrix *X);
+
+/* ---------------------------------------------------------------------------------
+ * One ingestion and one pair of tiled layouts per NODE instead of per process.  The reference ships the whole bundle,
+ * matrix included, to every MPI slave (R/bayesian.R:252-263); here the processes of a node (one per GPU) share the host's
+ * work through memory the caller maps into all of them (e.g. /dev/shm):
+ *   builder  : vbnmf_matrix_get_meta -> meta[8]; vbnmf_matrix_export_layout(buf = NULL) cuts (and caches) the layout of one
+ *              side and returns the blob size; a second call writes the blob into the shared buffer.
+ *   the rest : vbnmf_matrix_shell(meta) -- a handle with X's dimensions and constants but NO entries -- then
+ *              vbnmf_matrix_import_layout for each side; engines created on it (whole matrix, that geometry) upload the
+ *              imported arrays to their own GPU.  Entry points that need entries (partition engines, _csc, _write_mtx,
+ *              _empty_counts, vbnmf_layout_build) answer VBNMF_ERR_STATE on a shell.
+ * meta = {n, m, stored entries, all-integer flag, packed-count flag, max value, sum lgamma(x+1), sum(-x log x + x)}.
+ * geometry_rank and n_wg must be what the engines will use (vbnmf_engine_create_geom, vbnmf_device_sweep_workgroups).
+ * --------------------------------------------------------------------------------- */
+int vbnmf_matrix_get_meta(const vbnmf_matrix *X, double *meta);
+int vbnmf_matrix_shell(const double *meta, vbnmf_matrix **out);
+int vbnmf_matrix_is_shell(const vbnmf_matrix *X);
+int vbnmf_matrix_export_layout(const vbnmf_matrix *X, int32_t side, int32_t geometry_rank, int32_t n_wg,
+                               void *buf, int64_t capacity, int64_t *bytes);
+int vbnmf_matrix_import_layout(const vbnmf_matrix *X, const void *buf, int64_t bytes);
+/* Persistent workgroups of the sweep kernels on `device` (one per CU; VBNMF_NWG overrides): the n_wg of the layouts
+ * that whole-matrix engines on that device use. */
+int vbnmf_device_sweep_workgroups(int32_t device, int32_t *n_wg);
 
 /* ---------------------------------------------------------------------------------
  * Engine: device-resident state of one factorisation of (a column block of) X at one
@@ -119,6 +148,11 @@ int vbnmf_engine_create(const vbnmf_matrix *X, int32_t r, int32_t device, vbnmf_
  * the reduce buffer (below) across partitions between step_local and step_finish. */
 int vbnmf_engine_create_part(const vbnmf_matrix *X, int64_t col_begin, int64_t col_end,
                              int64_t m_global, int32_t r, int32_t device, vbnmf_engine **out);
+/* The same with the layouts' geometry named per ENGINE: geometry_rank >= r is the rank whose LDS row size the tiled
+ * layouts are cut for (the ranks of a sweep, R/bayesian.R:316, share one pair: vbnmf_plan_classes); 0 = the class of the
+ * matrix's plan (vbnmf_matrix_plan_ranks), the rank's own geometry without one. */
+int vbnmf_engine_create_geom(const vbnmf_matrix *X, int64_t col_begin, int64_t col_end, int64_t m_global, int32_t r,
+                             int32_t geometry_rank, int32_t device, vbnmf_engine **out);
 void vbnmf_engine_destroy(vbnmf_engine *e);
 
 /* n, local m (cells owned), r. */
@@ -258,9 +292,11 @@ int vbnmf_update_dense(int64_t n, int64_t m, int32_t r, const double *X,
                        double *lw, double *lh, double *ew, double *eh,
                        double *dw, double *dh, double *lkh);
 /* The stateless entries (these two and vbnmf_ml_update_*) keep the LAST ingested matrix and its engine alive between
- * calls, keyed by the content of X (dimensions + a 64-bit hash of every byte handed in): the reference's loop passes
- * the same X thousands of times (R/bayesian.R:339), and a repeat then costs the hash, the state transfer and one step
- * instead of ingestion + layouts + engine.  Results do not depend on it.  VBNMF_STATELESS_CACHE=0 disables it;
+ * calls, keyed by the content of X: the dimensions, TWO independently seeded 64-bit hashes of every byte handed in (the
+ * seed starts every chunk digest, so contents colliding under one seed do not under the other: a 128-bit key) and, on a
+ * hit, a comparison of the CSC pointer array resp. of a strided sample (<= 4096 values) of the dense X.  The reference's
+ * loop passes the same X thousands of times (R/bayesian.R:339), and a repeat then costs the hashes, the state transfer
+ * and one step instead of ingestion + layouts + engine.  Results do not depend on it.  VBNMF_STATELESS_CACHE=0 disables it;
  * vbnmf_stateless_cache_clear() releases what is held (device and host memory). */
 void vbnmf_stateless_cache_clear(void);
 /* Same with X as dgCMatrix slots (no densification on the R side). */
@@ -390,6 +426,10 @@ typedef struct {
     const uint32_t *packed;        /* [n_slots] (count << 18) | (local minor * row_slots << 4)   (wide == 0) */
     const uint32_t *wide_idx;      /* [n_slots] local minor                    (wide == 1) */
     const double *wide_val;        /* [n_slots]                                (wide == 1) */
+    const int32_t *cell_perm;      /* [cells of the column range] or NULL: the layout's internal renumbering of the cells
+                                      (minors on side 0, majors on side 1): position -> column relative to col_begin.
+                                      NULL = as stored.  Cells with alike gene support are stored next to each other, so
+                                      a gene's entries fall into fewer cell blocks (csrc/order.cpp; VBNMF_CELL_ORDER=0/1). */
 } vbnmf_layout_view;
 
 int vbnmf_layout_build(const vbnmf_matrix *X, int64_t col_begin, int64_t col_end, int32_t side,
@@ -411,6 +451,8 @@ int vbnmf_test_special_device(int32_t kind, int64_t n, const double *x, double *
  * message naming the last completed step, and the engine is left untouched (its destroy neither waits nor frees while
  * work is still queued).  The reference has no analogue: its call is synchronous CPU code (src/RcppExports.cpp:11-22). */
 int vbnmf_test_stream_sleep(vbnmf_engine *e, double seconds);
+/* Test hook (host only): the stateless cache's content hash of `bytes` bytes under `seed`. */
+uint64_t vbnmf_test_hash_bytes(const void *data, int64_t bytes, uint64_t seed);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,210 @@
+// fake_rccl.cpp -- TEST INFRASTRUCTURE, not a product fallback: a stand-in for librccl that lets TWO (or more) processes
+// on ONE GPU run the library's RCCL protocol (ccfindr_amd/csrc/comm.h opens it when VBNMF_RCCL_LIB names it).  Real RCCL
+// refuses two ranks on a device and the test box has one GPU, so without this the code that only runs with nranks > 1 --
+// vbnmf_comm_create, queue_vb_step's RCCL branch, the event ring, drive_loop's replicated queueing, the bounded waits
+// with a dead peer -- would first execute on the driver's 8-GPU node.  The product keeps real RCCL over xGMI.
+//
+// Exports the eight symbols comm.h binds, with RCCL's signatures.  A collective is STREAM-ORDERED like the real one:
+//   hipMemcpyAsync(device -> this rank's slot in a shared-memory segment)        on the caller's stream
+//   hipLaunchHostFunc: publish "slot k ready", wait for every rank's, sum the slots IN RANK ORDER into a private
+//                      pinned buffer, publish "read k", wait for every rank's (then the slots may be overwritten)
+//   hipMemcpyAsync(private buffer -> device)
+// so kernels queued behind it on the stream see the reduced data, kernels on other streams run beside it, and a rank
+// whose peer never arrives stays on hipErrorNotReady -- exactly what the library's timeouts must handle.  The wait inside
+// the host function gives up after FAKE_RCCL_TIMEOUT_S (default 60) so that a process can still exit.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fcntl.h>
+#include <string>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <thread>
+#include <unistd.h>
+
+namespace {
+
+constexpr int kMaxRanks = 8;
+constexpr size_t kSlotBytes = (size_t)64 << 20;          // per rank; the segment is sparse until written
+constexpr size_t kHeaderBytes = 4096;
+
+struct Header {
+    std::atomic<uint32_t> arrived;                       // ranks that mapped the segment
+    std::atomic<uint32_t> left;                          // ranks that destroyed their communicator
+    std::atomic<uint64_t> ready[kMaxRanks];              // ops whose input slot is complete, per rank
+    std::atomic<uint64_t> read[kMaxRanks];               // ops whose inputs this rank has finished reading
+};
+static_assert(sizeof(Header) <= kHeaderBytes, "header too large");
+
+struct Comm {
+    int nranks = 0, rank = 0;
+    std::string path;
+    char *base = nullptr;
+    size_t bytes = 0;
+    Header *h = nullptr;
+    bool pinned = false;
+    double *result = nullptr;                            // private pinned staging buffer of the reduced data
+    uint64_t ops = 0;                                    // collectives enqueued so far (host thread)
+    std::atomic<int> broken{0};
+    double timeout_s = 60.0;
+};
+
+struct Op {
+    Comm *c;
+    uint64_t k;
+    size_t count;
+    int root;                                            // < 0: all-reduce (sum); >= 0: broadcast from root
+};
+
+char *slot(Comm *c, int r) { return c->base + kHeaderBytes + (size_t)r * kSlotBytes; }
+
+bool wait_all(Comm *c, std::atomic<uint64_t> *arr, uint64_t want)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (long spins = 0;; spins++) {
+        bool ok = true;
+        for (int r = 0; r < c->nranks; r++) ok = ok && arr[r].load(std::memory_order_acquire) >= want;
+        if (ok) return true;
+        if (c->broken.load()) return false;
+        if ((spins & 0x3FF) == 0) {
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > c->timeout_s) {
+                c->broken.store(1);
+                fprintf(stderr, "[fake_rccl] rank %d gave up waiting for its peers after %.0f s\n", c->rank, c->timeout_s);
+                return false;
+            }
+            std::this_thread::yield();
+        }
+    }
+}
+
+void host_reduce(void *arg)
+{
+    Op *op = static_cast<Op *>(arg);
+    Comm *c = op->c;
+    c->h->ready[c->rank].store(op->k + 1, std::memory_order_release);
+    if (wait_all(c, c->h->ready, op->k + 1)) {
+        if (op->root >= 0) {
+            std::memcpy(c->result, slot(c, op->root), op->count * sizeof(double));
+        } else {
+            const double *s0 = reinterpret_cast<const double *>(slot(c, 0));
+            for (size_t i = 0; i < op->count; i++) c->result[i] = s0[i];
+            for (int r = 1; r < c->nranks; r++) {                       // rank order: every rank forms the same bits
+                const double *s = reinterpret_cast<const double *>(slot(c, r));
+                for (size_t i = 0; i < op->count; i++) c->result[i] += s[i];
+            }
+        }
+        c->h->read[c->rank].store(op->k + 1, std::memory_order_release);
+        (void)wait_all(c, c->h->read, op->k + 1);
+    }
+    delete op;
+}
+
+ncclResult_t collective(const void *send, void *recv, size_t count, ncclDataType_t dt, int root, ncclComm_t comm, hipStream_t stream)
+{
+    Comm *c = reinterpret_cast<Comm *>(comm);
+    if (!c || dt != ncclDouble) return ncclInvalidArgument;
+    if (count * sizeof(double) > kSlotBytes) return ncclInvalidArgument;
+    if (c->broken.load()) return ncclSystemError;
+    Op *op = new Op{c, c->ops++, count, root};
+    if (hipMemcpyAsync(slot(c, c->rank), send, count * sizeof(double), hipMemcpyDeviceToHost, stream) != hipSuccess) return ncclUnhandledCudaError;
+    if (hipLaunchHostFunc(stream, host_reduce, op) != hipSuccess) return ncclUnhandledCudaError;
+    if (hipMemcpyAsync(recv, c->result, count * sizeof(double), hipMemcpyHostToDevice, stream) != hipSuccess) return ncclUnhandledCudaError;
+    return ncclSuccess;
+}
+
+}  // namespace
+
+extern "C" {
+
+ncclResult_t ncclGetUniqueId(ncclUniqueId *id)
+{
+    if (!id) return ncclInvalidArgument;
+    static std::atomic<unsigned> counter{0};
+    std::memset(id, 0, sizeof *id);
+    const auto now = std::chrono::steady_clock::now().time_since_epoch().count();
+    snprintf(id->internal, sizeof id->internal, "fake_rccl_%d_%u_%llx", (int)getpid(), counter++, (unsigned long long)now);
+    return ncclSuccess;
+}
+
+ncclResult_t ncclCommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId id, int rank)
+{
+    if (!comm || nranks < 1 || nranks > kMaxRanks || rank < 0 || rank >= nranks) return ncclInvalidArgument;
+    id.internal[sizeof id.internal - 1] = 0;
+    Comm *c = new Comm();
+    c->nranks = nranks; c->rank = rank;
+    if (const char *s = getenv("FAKE_RCCL_TIMEOUT_S")) { const double v = atof(s); if (v > 0) c->timeout_s = v; }
+    c->path = std::string("/dev/shm/") + id.internal;
+    c->bytes = kHeaderBytes + (size_t)nranks * kSlotBytes;
+    const int fd = open(c->path.c_str(), O_CREAT | O_RDWR, 0600);      // whoever comes first creates it (zero-filled)
+    if (fd < 0 || ftruncate(fd, (off_t)c->bytes) != 0) { if (fd >= 0) close(fd); delete c; return ncclSystemError; }
+    c->base = static_cast<char *>(mmap(nullptr, c->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0));
+    close(fd);
+    if (c->base == MAP_FAILED) { delete c; return ncclSystemError; }
+    c->h = reinterpret_cast<Header *>(c->base);
+    // pinning this rank's slot makes the device -> host copy a true asynchronous, stream-ordered DMA
+    c->pinned = hipHostRegister(slot(c, rank), kSlotBytes, hipHostRegisterDefault) == hipSuccess;
+    if (!c->pinned) (void)hipGetLastError();
+    if (hipHostMalloc(reinterpret_cast<void **>(&c->result), kSlotBytes, hipHostMallocDefault) != hipSuccess) {
+        munmap(c->base, c->bytes); delete c; return ncclUnhandledCudaError;
+    }
+    c->h->arrived.fetch_add(1);
+    const auto t0 = std::chrono::steady_clock::now();                  // like the real call: returns once every rank is there
+    while (c->h->arrived.load() < (uint32_t)nranks) {
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > c->timeout_s) {
+            fprintf(stderr, "[fake_rccl] rank %d: only %u of %d ranks arrived\n", rank, c->h->arrived.load(), nranks);
+            (void)hipHostFree(c->result); munmap(c->base, c->bytes); delete c;
+            return ncclSystemError;
+        }
+        std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    }
+    if (rank == 0) unlink(c->path.c_str());                            // every rank holds its mapping: the name can go
+    *comm = reinterpret_cast<ncclComm_t>(c);
+    return ncclSuccess;
+}
+
+ncclResult_t ncclCommDestroy(ncclComm_t comm)
+{
+    Comm *c = reinterpret_cast<Comm *>(comm);
+    if (!c) return ncclSuccess;
+    c->broken.store(1);                                                // a host function still waiting leaves at once
+    c->h->left.fetch_add(1);
+    if (c->pinned) (void)hipHostUnregister(slot(c, c->rank));
+    (void)hipHostFree(c->result);
+    munmap(c->base, c->bytes);
+    delete c;
+    return ncclSuccess;
+}
+
+ncclResult_t ncclAllReduce(const void *send, void *recv, size_t count, ncclDataType_t dt, ncclRedOp_t op, ncclComm_t comm, hipStream_t stream)
+{
+    if (op != ncclSum) return ncclInvalidArgument;
+    return collective(send, recv, count, dt, -1, comm, stream);
+}
+
+ncclResult_t ncclBroadcast(const void *send, void *recv, size_t count, ncclDataType_t dt, int root, ncclComm_t comm, hipStream_t stream)
+{
+    Comm *c = reinterpret_cast<Comm *>(comm);
+    if (!c || root < 0 || root >= c->nranks) return ncclInvalidArgument;
+    return collective(send, recv, count, dt, root, comm, stream);
+}
+
+ncclResult_t ncclGroupStart() { return ncclSuccess; }
+ncclResult_t ncclGroupEnd() { return ncclSuccess; }
+
+const char *ncclGetErrorString(ncclResult_t r)
+{
+    switch (r) {
+        case ncclSuccess: return "no error";
+        case ncclUnhandledCudaError: return "fake_rccl: a HIP call failed";
+        case ncclSystemError: return "fake_rccl: system error (shared memory, or a peer never arrived)";
+        case ncclInvalidArgument: return "fake_rccl: invalid argument";
+        default: return "fake_rccl: error";
+    }
+}
+
+}  // extern "C"

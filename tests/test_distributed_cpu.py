@@ -123,3 +123,49 @@ def test_sharded_sweep_unit_failure_reaches_every_rank():
         assert p.exitcode == 0
     assert outs[0][1] == outs[1][1]
     assert "rank 3" in outs[0][1] and "failed to converge" in outs[0][1] and "process 1" in outs[0][1]
+
+
+def _two_node_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ["VBNMF_NODE_KEY"] = f"pretend-node-{rank}"          # no shared /dev/shm between the two processes
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fake_engine import NumpyPhaseEngine
+        from ccfindr_amd import parallel
+        X = _data()
+        tm = {}
+        res = parallel.vb_factorize_sharded(X, ranks=[2, 3, 4], nrun=1, Itmax=15, seed=11, timings=tm,
+                                            engine_factory=lambda M, rk: NumpyPhaseEngine(X, rk))
+        q.put((rank, res.ranks, res.measure, res.nsteps, [np.asarray(b).copy() for b in res.basis],
+               [np.asarray(b).copy() for b in res.dcoeff], tm))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_sweep_across_two_pretend_nodes_uses_tensor_broadcasts():
+    """Processes that share no /dev/shm (forced through VBNMF_NODE_KEY): a unit's factor matrices reach the other node by
+    tensor broadcast from its owner; the result is still the serial one, bit for bit, on every process."""
+    sys.path.insert(0, HERE)
+    from fake_engine import NumpyPhaseEngine
+    import ccfindr_amd as C
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 32700 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_two_node_worker, args=(k, 2, port, q)) for k in range(2)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=240) for _ in procs], key=lambda o: o[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    X = _data()
+    serial = C.vb_factorize(X, ranks=[2, 3, 4], nrun=1, verbose=0, Itmax=15, seed=11,
+                            engine_factory=lambda M, rk: NumpyPhaseEngine(X, rk))
+    for rank, ranks, measure, nsteps, basis, dcoeff, tm in outs:
+        assert tm["node_processes"] == 1
+        assert ranks == serial.ranks and nsteps == serial.nsteps and measure == serial.measure
+        for a, b in zip(basis, serial.basis):
+            assert np.array_equal(a, b)
+        for a, b in zip(dcoeff, serial.dcoeff):
+            assert np.array_equal(a, b)

@@ -163,10 +163,14 @@ def _c4_worker(rank, world, port, path, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from ccfindr_amd import parallel
-        z = np.load(path, mmap_mode="r")
-        X = sp.csc_matrix((np.asarray(z["data"]), np.asarray(z["indices"]), np.asarray(z["indptr"])), shape=tuple(z["shape"]))
-        res = parallel.vb_factorize_sharded(X, ranks=[4, 10, 17], nrun=1, Itmax=12, seed=11, device=0)
-        q.put((rank, res.ranks, res.measure, res.nsteps, [np.asarray(b).copy() for b in res.basis]))
+        X = None                                  # process 0 alone holds (and ingests) X; the other runs on a shell
+        if rank == 0:
+            z = np.load(path, mmap_mode="r")
+            X = sp.csc_matrix((np.asarray(z["data"]), np.asarray(z["indices"]), np.asarray(z["indptr"])), shape=tuple(z["shape"]))
+        tm = {}
+        res = parallel.vb_factorize_sharded(X, ranks=[4, 10, 17], nrun=1, Itmax=12, seed=11, device=0, timings=tm)
+        q.put((rank, res.ranks, res.measure, res.nsteps, [np.asarray(b).copy() for b in res.basis],
+               [np.asarray(b).copy() for b in res.dcoeff], tm))
     finally:
         dist.destroy_process_group()
 
@@ -174,6 +178,8 @@ def _c4_worker(rank, world, port, path, q):
 def test_config4_sharded_sweep_two_processes_on_the_headline_matrix(c3, tmp_path):
     """vb_factorize_sharded (LPT over the units, no data-path collective) across two processes on the C3 matrix, ranks
     4 / 10 / 17, 12 iterations each: every process must return what the single-process vb_factorize returns, bit for bit.
+    Only process 0 ingests X and cuts the sweep's pair of layouts; process 1 works on a SHELL with the layouts imported
+    through /dev/shm, and both read every unit's factor matrices from the node's shared result segment.
     (Both processes share the one test GPU; on the 8-GPU node each has its own.)"""
     import torch.multiprocessing as mp
     import ccfindr_amd as C
@@ -192,9 +198,12 @@ def test_config4_sharded_sweep_two_processes_on_the_headline_matrix(c3, tmp_path
         p.join(timeout=120)
         assert p.exitcode == 0
     assert all(np.isfinite(v) for v in single.measure["lml"])
-    for _, ranks, measure, nsteps, basis in outs:
+    assert [o[-1]["is_shell"] for o in outs] == [False, True] and all(o[-1]["node_processes"] == 2 for o in outs)
+    for _, ranks, measure, nsteps, basis, dcoeff, _tm in outs:
         assert ranks == single.ranks and nsteps == single.nsteps and measure == single.measure
         for a, b in zip(basis, single.basis):
+            assert np.array_equal(a, b)
+        for a, b in zip(dcoeff, single.dcoeff):
             assert np.array_equal(a, b)
 
 

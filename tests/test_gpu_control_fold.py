@@ -137,3 +137,32 @@ def test_ml_loop_fold_and_separate_control_agree_bit_for_bit(problem, Itmax, Tol
         assert outs[0][0]["it"] == Itmax and outs[0][0]["reason"] == 4
     assert outs[0][2] == outs[1][2]
     assert np.array_equal(outs[0][3], outs[1][3]) and np.array_equal(outs[0][4], outs[1][4])
+
+
+@pytest.mark.parametrize("Itmax", [5, 16, 23, 40])
+def test_a_drained_stream_is_not_mistaken_for_a_lost_step(problem, Itmax):
+    """with the fold, step t is reported by step t + 1's launch, so a stream that has DRAINED before the host
+    looks (a stalled host thread: VBNMF_TEST_DRAIN_BEFORE_POLL synchronises the stream in front of every poll) shows
+    queued - 1 completed steps while more are still to be queued.  The idle check used to call that "the device went idle
+    before the queued steps finished"; the run must complete and equal the undisturbed one, for the VB and the ML loop."""
+    from ccfindr_amd import synth
+    M, n, m = problem
+    r = 4
+    wh = synth.random_state(n, m, r, HY, seed=6)
+    rng = np.random.default_rng(3)
+    w0, h0 = rng.uniform(size=(n, r)), rng.uniform(size=(r, m))
+    outs = []
+    for drain in ("0", "1"):
+        os.environ["VBNMF_TEST_DRAIN_BEFORE_POLL"] = drain
+        try:
+            eng = _engine(M, r, wh, True)
+            vb = eng.run(HY, Itmax=Itmax, Tol=0.0, n0=3, dn=1, flags=(True,) * 4, history=True)
+            eng.ml_set_state(w0, h0)
+            ml = eng.ml_run(Itmax=Itmax, Tol=0.0, history=True)
+            eng.close()
+        finally:
+            del os.environ["VBNMF_TEST_DRAIN_BEFORE_POLL"]
+        outs.append((vb, ml))
+    _same(outs[0][0], outs[1][0])
+    assert outs[0][0]["it"] == Itmax
+    assert outs[0][1]["it"] == outs[1][1]["it"] == Itmax and np.array_equal(outs[0][1]["history"], outs[1][1]["history"])

@@ -48,6 +48,15 @@ def test_host_stepped_wait_times_out_with_the_last_completed_step(short_limit):
     assert ei.value.code == N.ERR_HIP
     assert "timed out" in str(ei.value) and "last completed step" in str(ei.value)
     assert 0.9 < waited < 2.5, waited
+    # the engine is unusable from here on, and every entry point says so AT ONCE instead of blocking on a
+    # stream that may never drain (get_state's memcpy, set_state's synchronise, another step)
+    t0 = time.perf_counter()
+    for call in (lambda: eng.get_state(), lambda: eng.step(HY), lambda: eng.run(HY, Itmax=3),
+                 lambda: eng.set_state(np.ones((eng.n, 4)), np.ones((4, eng.m)), np.ones((4, eng.m)))):
+        with pytest.raises(N.VBNMFError) as e2:
+            call()
+        assert e2.value.code == N.ERR_STATE and "timed out earlier" in str(e2.value)
+    assert time.perf_counter() - t0 < 0.5
     time.sleep(3.0)                                          # the sleeper ends, the queued step drains
     eng.close()
     M.close()

@@ -1,0 +1,160 @@
+"""One ingestion and one pair of layouts per NODE (no GPU needed for the host side): the layout blob round trip through a
+/dev/shm segment into a matrix SHELL, the shell's refusals, the rank classes as a pure function, and the stateless
+cache's two independent content hashes.  Reference behaviour replaced: the whole bundle shipped to every MPI slave,
+/root/reference R/bayesian.R:252-263."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+
+def _matrix(seed=4, wide=False):
+    from ccfindr_amd import synth
+    X = synth.fill_empty(synth.simulate_data(700, [400, 500, 300], alpha0=0.2, seed=seed, depth=np.full(1200, 90)), seed=seed)
+    if wide:
+        X = X.astype(np.float64) * 0.37
+    return X
+
+
+def _layout_view(M, side, r):
+    from ccfindr_amd import _native as N
+    L = N.load()
+    h, v = ctypes.c_void_p(), N.LayoutView()
+    N.check(L.vbnmf_layout_build(M._h, 0, M.shape[1], side, r, ctypes.byref(h), ctypes.byref(v)))
+    return h, v
+
+
+@pytest.mark.parametrize("wide", [False, True])
+def test_layout_blob_round_trip_through_shared_memory(wide):
+    """export -> /dev/shm segment -> import into a shell: the imported layout is accepted in place of a cut one, and a blob
+    exported again FROM the shell is byte-identical to the original (every array and scalar survived)."""
+    import ccfindr_amd as C
+    from ccfindr_amd import node
+    M = C.CountMatrix(_matrix(wide=wide))
+    meta = M.meta()
+    assert meta[0] == M.shape[0] and meta[1] == M.shape[1] and meta[2] == M.nnz and meta[6] == M.sum_lgamma_x1
+    S = C.CountMatrix.shell(meta)
+    assert S.is_shell and not M.is_shell and S.shape == M.shape and S.nnz == M.nnz
+    for side in (0, 1):
+        nb = M.layout_blob_size(side, 12, 256)
+        seg = node.Segment.create(node.fresh_name("t"), nb)
+        try:
+            assert M.export_layout(side, 12, 256, seg.map) == nb
+            peer = node.Segment.open(seg.name)
+            S.import_layout(peer.map, nb)
+            back = bytearray(nb)
+            assert S.export_layout(side, 12, 256, back) == nb          # from the shell's cache: no entries needed
+            assert bytes(back) == bytes(seg.map[:nb])
+            peer.close()
+        finally:
+            seg.close()
+        assert not os.path.exists(os.path.join(node.shm_dir(), seg.name))
+    S.close(); M.close()
+
+
+def test_shell_refuses_what_needs_entries_and_unknown_geometries():
+    import ccfindr_amd as C
+    from ccfindr_amd import _native as N
+    M = C.CountMatrix(_matrix())
+    S = C.CountMatrix.shell(M.meta())
+    for call in (S.empty_counts, S.to_scipy, lambda: S.write_mtx("/tmp/never.mtx"), lambda: _layout_view(S, 0, 4),
+                 lambda: S.layout_blob_size(0, 6, 256)):                # nothing imported for that geometry
+        with pytest.raises(N.VBNMFError) as ei:
+            call()
+        assert ei.value.code == N.ERR_STATE and "shell" in str(ei.value)
+    # a blob of another matrix, a truncated blob and a corrupted closing word are all refused
+    nb = M.layout_blob_size(1, 6, 256)
+    blob = bytearray(nb)
+    M.export_layout(1, 6, 256, blob)
+    other = C.CountMatrix.shell(np.array([M.shape[0], M.shape[1] + 1, M.nnz, 1, 1, 5, 0, 0], dtype=float))
+    for target, data in ((other, blob), (S, blob[:nb - 64]), (S, blob[:nb - 8] + b"\0" * 8)):
+        with pytest.raises(N.VBNMFError) as ei:
+            target.import_layout(data)
+        assert ei.value.code == N.ERR_BAD_ARG
+    S.import_layout(blob)                                               # the intact one goes in
+    assert S.layout_blob_size(1, 6, 256) == nb
+    other.close(); S.close(); M.close()
+
+
+def test_rank_classes_are_a_pure_function_and_match_the_matrix_plan():
+    """vbnmf_plan_classes / vbnmf_padded_rank: what vb_factorize hands to each engine instead of mutating the matrix."""
+    import ccfindr_amd as C
+    from ccfindr_amd.engine import geometry_rank_for, rank_classes
+    assert rank_classes(range(2, 21)) == [20]
+    assert rank_classes([3, 10, 20], 2) == [10, 20]                     # rows of rank 10 are at most half as wide as 20's
+    assert rank_classes([5]) == [6] and rank_classes([]) == []
+    assert rank_classes([33, 70], 1) == [80]
+    assert [geometry_rank_for(r, [10, 20]) for r in (2, 9, 10, 11, 20)] == [10, 10, 10, 20, 20]
+    assert geometry_rank_for(21, [10, 20]) == 0 and geometry_rank_for(7, []) == 0
+    # the same classes as a plan on the matrix gives (layout geometry of rank 3 under [3, 10, 20])
+    M = C.CountMatrix(_matrix())
+    h0, v0 = _layout_view(M, 0, 20)
+    want = (v0.row_slots, v0.block_width)
+    C.load().vbnmf_layout_destroy(h0)
+    M.plan_ranks([3, 10, 20])
+    h1, v1 = _layout_view(M, 0, 3)
+    assert (v1.row_slots, v1.block_width) == want
+    C.load().vbnmf_layout_destroy(h1)
+    M.close()
+
+
+def test_vb_factorize_leaves_a_callers_plan_alone():
+    """vb_factorize used to set its own plan on the caller's CountMatrix and clear it afterwards."""
+    import ccfindr_amd as C
+    from fake_engine import NumpyPhaseEngine
+    X = _matrix().toarray()[:60, :80]
+    X = X[X.sum(1) > 0][:, X[X.sum(1) > 0].sum(0) > 0]
+    M = C.CountMatrix(X)
+    M.plan_ranks([2, 6])
+    h, before = _layout_view(M, 1, 2)
+    stride = before.row_slots
+    C.load().vbnmf_layout_destroy(h)
+    C.vb_factorize(M, ranks=[2, 3], nrun=1, verbose=0, Itmax=3, seed=5, engine_factory=lambda mm, rk: NumpyPhaseEngine(X, rk))
+    h, after = _layout_view(M, 1, 2)
+    assert after.row_slots == stride                                    # still the plan [2, 6]: stride of rank 6
+    C.load().vbnmf_layout_destroy(h)
+    M.close()
+
+
+# ---- the stateless cache's key ------------------------------------------------------------
+MASK = (1 << 64) - 1
+
+
+def _chunk_digest(words, seed, c=0):
+    """ccfindr_amd/csrc/engine.hip hash_bytes, one chunk of whole 8-byte words."""
+    h = (seed ^ 0x9E3779B97F4A7C15 ^ ((c * 0xD6E8FEB86659FD93) & MASK)) & MASK
+    trace = []
+    for w in words:
+        trace.append(h)
+        h = ((h ^ w) * 0xFF51AFD7ED558CCD) & MASK
+        h ^= h >> 32
+    return h, trace
+
+
+def test_two_seeds_give_independent_hashes():
+    """Two buffers built to collide in their chunk digest under seed A (the second word of the second buffer cancels the
+    state difference the first word made) hash alike under A and differently under B: the key is 128 bits, not 64."""
+    from ccfindr_amd import _native as N
+    L = N.load()
+    A, B = 0x64656E7365, 0x3243F6A8885A308D
+    rng = np.random.default_rng(5)
+    w = [int(v) for v in rng.integers(0, 1 << 63, size=6, dtype=np.int64)]
+    v = list(w)
+    v[2] ^= 0x5DEECE66D                                                  # differ at word 2 ...
+    _, tw = _chunk_digest(w[:4], A)
+    _, tv = _chunk_digest(v[:4], A)
+    v[3] = w[3] ^ tw[3] ^ tv[3]                                          # ... and cancel the state difference at word 3
+    assert _chunk_digest(w, A)[0] == _chunk_digest(v, A)[0] and w != v
+
+    def lib_hash(words, seed):
+        buf = np.asarray(words, dtype=np.uint64)
+        return int(L.vbnmf_test_hash_bytes(buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes, seed))
+
+    assert lib_hash(w, A) == lib_hash(v, A)                              # the constructed collision is real ...
+    assert lib_hash(w, B) != lib_hash(v, B)                              # ... and the second seed tells the buffers apart
+    assert lib_hash(w, A) != lib_hash(w, B)

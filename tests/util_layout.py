@@ -30,6 +30,8 @@ def build_layout(M, side, r, cols=None):
         out["wg_seg0"] = arr(v.wg_seg0, v.n_wg + 1)
         out["inv_ptr"] = arr(v.inv_ptr, v.n_major + 1)
         out["inv_task"] = arr(v.inv_task, v.n_tasks)
+        ncell = v.n_minor if v.side == 0 else v.n_major
+        out["cell_perm"] = arr(v.cell_perm, ncell) if v.cell_perm else None     # position -> column (None: as stored)
         if v.wide:
             out["wide_idx"] = arr(v.wide_idx, v.n_slots)
             out["wide_val"] = arr(v.wide_val, v.n_slots)
@@ -41,7 +43,8 @@ def build_layout(M, side, r, cols=None):
 
 
 def reconstruct(view):
-    """Dense [n_major, n_minor] matrix the layout encodes; checks the structural invariants on the way."""
+    """Dense [n_major, n_minor] matrix the layout encodes, in X's own numbering of the cells (the layout's internal
+    renumbering, view["cell_perm"], is undone at the end); checks the structural invariants on the way."""
     A = np.zeros((view["n_major"], view["n_minor"]))
     nslot = np.zeros(A.shape, dtype=np.int64)          # slots per (major, minor)
     npart = np.zeros(A.shape, dtype=np.int64)          # ... of which not a full 16383 piece
@@ -119,6 +122,15 @@ def reconstruct(view):
     for g in range(view["n_segs"]):
         assert (view["slice_block"][ptr[g]:ptr[g + 1]] == view["seg_block"][g]).all()
         assert np.all(np.diff(view["slice_width"][ptr[g]:ptr[g + 1]]) <= 0)
+    perm = view.get("cell_perm")
+    if perm is not None:
+        assert sorted(perm.tolist()) == list(range(perm.size))          # a permutation of the cells
+        B = np.empty_like(A)
+        if view["side"] == 0:
+            B[:, perm] = A                                              # minor position p holds column perm[p]
+        else:
+            B[perm, :] = A
+        A = B
     return A
 
 
