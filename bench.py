@@ -31,6 +31,11 @@ a short K measures the chip at its loaded clocks, not on its way up from idle.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--mode restarts|cells] [--small]
 
+Beside the headline, at every N: `rank_sweep` = BASELINE config C4 (ranks 2..20 on the same matrix through
+vb_factorize_sharded, reference defaults: wall seconds, per-rank iterations, stepping / setup split per process); at N > 1
+also `cells_partitioned` = config C5 (one factorisation, cells partitioned N-way, the library's all-reduce inside the
+device-driven loop) with its per-GPU roofline and `allreduce_ms` (events around the collective).
+
 N > 1 (one process per GPU under torch.distributed.run; a BARE `python bench.py --gpus N` starts those ranks itself as a
 child process -- before torch is imported or the GPU touched -- relays rank 0's line and exits with their status):
   --mode restarts (default)  every GPU runs an independent restart of the same factorisation
@@ -136,40 +141,131 @@ def cpu_reference_literal(X, r, wh0, cells=2000, reps=2):
             "extrapolated_s_per_iteration_full_size": dt * m / cells}
 
 
-def cells_partitioned_sample(world, rank, local_rank, barrier, steps):
+def make_c5(small):
+    from ccfindr_amd import synth
+    if small:
+        n, m, r, k, mean_depth = 3000, 16000, 20, 8, 200.0
+    else:
+        n, m, r, k, mean_depth = 30000, 200000, 20, 20, 1950.0
+    depth = np.round(np.random.default_rng(5).lognormal(np.log(mean_depth), 0.3, size=m)).astype(np.int64)
+    X = synth.fill_empty(synth.simulate_data(n, [m // k] * k, alpha0=0.1, seed=5, depth=depth), seed=5)
+    return X, n, m, r
+
+
+def cells_partitioned_sample(world, rank, local_rank, barrier, steps, small=False, check=True):
     """BASELINE config C5 as a side measurement of an N > 1 run: ONE factorisation of a 30 000 x 200 000 (~5 % stored)
     matrix at rank 20, cells partitioned over the N GPUs, the per-step all-reduce of [sw | rowSums(eh) | scalars] issued
-    by the library (RCCL over xGMI) inside the device-driven loop; strong scaling.  Rank 0 checks the first step's
-    evidence against the CPU oracle."""
+    by the library (RCCL over xGMI) inside the device-driven loop; strong scaling.  Beside the loop's rate: the per-GPU
+    roofline of a step (algorithmic bytes and flops of this GPU's partition over the step time, both fractions) and
+    `allreduce_ms`, the all-reduce alone (HIP events either side of vbnmf_engine_allreduce on the engine's stream, in a
+    host-stepped pass: in the loop it travels beside the cell-side sweep).  Rank 0 checks the first step's evidence
+    against the CPU oracle."""
+    import torch
     import ccfindr_amd as C
     from ccfindr_amd import synth
     from ccfindr_amd.parallel import CellPartitionedEngine
-    n, m, r, k = 30000, 200000, 20, 20
-    depth = np.round(np.random.default_rng(5).lognormal(np.log(1950.0), 0.3, size=m)).astype(np.int64)
-    X = synth.fill_empty(synth.simulate_data(n, [m // k] * k, alpha0=0.1, seed=5, depth=depth), seed=5)
+    X, n, m, r = make_c5(small)
     M = C.CountMatrix(X)
     eng = CellPartitionedEngine(M, r, device=local_rank)
     wh = synth.random_state(n, m, r, HYPER, seed=1005)
     eng.set_state(wh["lw"], wh["lh"], wh["eh"])
-    first = eng.run(HYPER, Itmax=5, Tol=0.0, flags=(False,) * 4, history=True)      # warm-up; history[0] is checked below
+    device_loop = eng.native or world == 1
+    first_lkh = None
     times = []
-    for _ in range(3):
-        barrier()
-        t0 = time.perf_counter()
-        res = eng.run(HYPER, Itmax=steps, Tol=0.0, flags=(False,) * 4)
-        barrier()
-        times.append(time.perf_counter() - t0)
-    out = {"workload": f"C5 {n} x {m} (~5 % stored, nnz {int(X.nnz)}), rank {r}, cells partitioned {world}-way",
-           "loop": "device-driven (vbnmf_engine_run + vbnmf_comm: ncclAllReduce enqueued from C++ beside the cell-side sweep)",
+    if device_loop:
+        first = eng.run(HYPER, Itmax=5, Tol=0.0, flags=(False,) * 4, history=True)      # warm-up; history[0] is checked below
+        first_lkh = float(first["history"][0, 0])
+        for _ in range(3):
+            barrier()
+            t0 = time.perf_counter()
+            res = eng.run(HYPER, Itmax=steps, Tol=0.0, flags=(False,) * 4)
+            barrier()
+            times.append(time.perf_counter() - t0)
+        lkh_last = res["lkh"]
+    else:
+        # a backend that cannot carry the library's collective (gloo rehearsals): host-stepped, exchange staged by torch
+        first_lkh, _ = eng.step(HYPER)
+        for _ in range(4):
+            eng.step(HYPER)
+        for _ in range(3):
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                lkh_last, _ = eng.step(HYPER)
+            barrier()
+            times.append(time.perf_counter() - t0)
+    # the all-reduce alone: events on the engine's stream either side of the collective, host-stepped
+    ar_ms = None
+    if eng.native:
+        ctx = eng.engine.stream_context
+        pairs = []
+        for _ in range(12):
+            eng.engine.step_local(HYPER)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            with ctx():
+                e0.record()
+            eng.engine.allreduce()
+            with ctx():
+                e1.record()
+            eng.engine.step_finish()
+            pairs.append((e0, e1))
+        torch.cuda.synchronize()
+        ar_ms = float(np.median([a.elapsed_time(b) for a, b in pairs[2:]]))
+    cb, ce = eng.cols
+    S = X.tocsc()
+    nnz_local = int(S.indptr[ce] - S.indptr[cb])
+    m_local = ce - cb
+    bytes_gpu = 12 * nnz_local + 4 * (n + 1) + 48 * (n * r + r * m_local)       # SURVEY section 8(d), this GPU's share
+    flops_gpu = 10 * r * nnz_local
+    out = {"workload": f"C5{'-small' if small else ''} {n} x {m} (~5 % stored, nnz {int(X.nnz)}), rank {r}, cells partitioned {world}-way",
+           "loop": ("device-driven (vbnmf_engine_run + vbnmf_comm: ncclAllReduce enqueued from C++ beside the cell-side sweep)"
+                    if device_loop else "host-stepped, exchange staged through torch.distributed (rehearsal backend)"),
+           "collective": ("library communicator: " + (os.environ.get("VBNMF_RCCL_LIB") and "stand-in named by VBNMF_RCCL_LIB (rehearsal)" or "RCCL"))
+                         if eng.native else "torch.distributed",
            "scaling": "strong", "steps": steps, "repeats_ms_per_step": [1e3 * t / steps for t in times],
-           "allreduce_bytes_per_step": 8 * (n * r + r + 4), "lkh_last": res["lkh"]}
+           "allreduce_bytes_per_step": 8 * (n * r + r + 4), "allreduce_ms": ar_ms, "lkh_last": lkh_last,
+           "per_gpu": {"cells": m_local, "nnz": nnz_local, "algorithmic_bytes_per_step": bytes_gpu, "flops_per_step": flops_gpu}}
     eng.close()
-    if rank == 0:
+    if rank == 0 and check:
         from oracle import vbnmf_oracle as O
-        S = X.tocsc()
         ref = O.update_csc(n, m, S.indptr, S.indices, S.data, wh, HYPER, nthreads=usable_cores())
-        out["lkh_rel_err_first_step_vs_cpu_oracle"] = abs(first["history"][0, 0] / ref["lkh"] - 1)
+        out["lkh_rel_err_first_step_vs_cpu_oracle"] = abs(first_lkh / ref["lkh"] - 1)
+    M.close()
     return out, times
+
+
+def rank_sweep_sample(M, world, rank, local_rank, barrier, small=False):
+    """BASELINE config C4: vb_factorize over ranks 2..20 on the headline matrix with the reference's defaults (hyper-parameter
+    updates on, Tol 1e-5), the (run, rank) units dealt longest-first over the N processes (one per GPU) -- no data-path
+    collective (reference R/bayesian.R:261-263, 316); one ingestion and one pair of layouts per node.  Wall seconds of the
+    call (slowest process), per-rank iterations, and per process the split into layouts / units / exchange and into device
+    stepping against everything else."""
+    import torch.distributed as dist
+    from ccfindr_amd import parallel
+    ranks = list(range(2, 7)) if small else list(range(2, 21))
+    tm = {}
+    barrier()
+    t0 = time.perf_counter()
+    res = parallel.vb_factorize_sharded(M, ranks=ranks, nrun=1, Itmax=2000, Tol=1e-5, seed=7, device=local_rank, timings=tm)
+    t_call = time.perf_counter() - t0
+    barrier()
+    t_wall = time.perf_counter() - t0
+    units = tm.get("unit_detail") or []
+    mine = {"process": rank, "call_s": t_call, "layouts_s": tm["layout_s"], "units_s": tm["units_s"], "exchange_s": tm["gather_s"],
+            "stepping_s": sum(u["loop_s"] for u in units), "ranks": [u["rank"] for u in units],
+            "layout_detail": tm.get("layout_detail")}
+    mine["setup_s"] = t_call - mine["stepping_s"]
+    rows = [mine]
+    if world > 1:
+        rows = [None] * world
+        dist.all_gather_object(rows, mine)                       # (small records; outside the timed call)
+    return {"workload": f"ranks {ranks[0]}..{ranks[-1]} on the headline matrix through vb_factorize_sharded, reference defaults "
+                        f"(hyper updates on, Tol 1e-5), {world} process(es)",
+            "wall_s": t_wall, "call_s_slowest_process": max(q["call_s"] for q in rows),
+            "stepping_s_total": sum(q["stepping_s"] for q in rows), "setup_s_slowest_process": max(q["setup_s"] for q in rows),
+            "iterations_by_rank": dict(zip([int(v) for v in res.ranks], [int(v) for v in res.nsteps])),
+            "iterations_total": int(sum(res.nsteps)),
+            "best_rank_by_lml": int(res.ranks[int(np.argmax(res.measure["lml"]))]), "per_process": rows}
 
 
 def timed_repeats(fn, barrier, repeats=5, after=None):
@@ -467,10 +563,20 @@ def main():
             k = min(len(cpu_lk), len(gpu_lk))
             if k:
                 out["elbo_rel_err_first_steps"] = max(abs(g / c - 1) for g, c in zip(gpu_lk[:k], cpu_lk[:k]))
+    # Config C4 beside the headline, at every N: the rank sweep through vb_factorize_sharded (no collective on its data path).
+    rank_sweep = None
+    if args.mode == "restarts" and args.rank == 0 and not os.environ.get("BENCH_NO_SWEEP"):
+        try:
+            eng.close()
+            rank_sweep = rank_sweep_sample(M, world, rank, local_rank, barrier, small=args.small)
+        except Exception as exc:                                   # noqa: BLE001 -- the headline must still be printed
+            rank_sweep = {"error": f"{type(exc).__name__}: {exc}"}
+        if rank == 0:
+            out["rank_sweep"] = rank_sweep
     # N > 1, default mode: after the headline (independent restarts, no collective) one C5-shaped cell-partitioned
     # factorisation is run on the same N GPUs, so that the RCCL path of the library is measured on hardware too.  It can
     # only hang where the fabric does, so the headline line is safe behind a watchdog that prints it and leaves.
-    if world > 1 and args.mode == "restarts" and backend == "nccl" and not args.small and not os.environ.get("BENCH_NO_CELLS"):
+    if world > 1 and args.mode == "restarts" and not os.environ.get("BENCH_NO_CELLS"):
         import threading
 
         def give_up():
@@ -487,13 +593,20 @@ def main():
         dog.start()
         try:
             eng.close()
-            cp, times = cells_partitioned_sample(world, rank, local_rank, barrier, max(50, min(args.steps, 300)))
-            t = torch.tensor(times, dtype=torch.float64, device="cuda")
+            cp, times = cells_partitioned_sample(world, rank, local_rank, barrier, max(50, min(args.steps, 300)) if not args.small else 20,
+                                                 small=args.small, check=not args.no_cpu)
+            t = torch.tensor(times, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             med = float(np.median(t.tolist()))
             cp["value"] = cp["steps"] / med
             cp["unit"] = "iterations/s"
             cp["ms_per_step"] = 1e3 * med / cp["steps"]
+            g = cp["per_gpu"]
+            cp["roofline"] = {"bound": "fp64-valu (rank 20) / hbm", "per": "GPU and step (whole step, all-reduce included)",
+                              "hbm": {"achieved": g["algorithmic_bytes_per_step"] / med * cp["steps"] / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": g["algorithmic_bytes_per_step"] / med * cp["steps"] / 1e9 / HBM_PEAK_GBS},
+                              "fp64": {"achieved": g["flops_per_step"] / med * cp["steps"] / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                       "frac": g["flops_per_step"] / med * cp["steps"] / 1e12 / FP64_PEAK_TFLOPS}}
             if rank == 0:
                 out["cells_partitioned"] = cp
         except Exception as exc:                                   # noqa: BLE001 -- the headline must still be printed

@@ -73,6 +73,9 @@ SIGNATURES = {
     "vbnmf_matrix_get_meta": (ctypes.c_int, [_VP, c_double_p]),
     "vbnmf_matrix_shell": (ctypes.c_int, [c_double_p, _VPP]),
     "vbnmf_matrix_is_shell": (ctypes.c_int, [_VP]),
+    "vbnmf_matrix_prepare": (ctypes.c_int, [_VP]),
+    "vbnmf_matrix_prepare_async": (ctypes.c_int, [_VP]),
+    "vbnmf_matrix_preload_layout": (ctypes.c_int, [_VP, _I32, _I32, _I32, _I32]),
     "vbnmf_matrix_export_layout": (ctypes.c_int, [_VP, _I32, _I32, _I32, _VP, _I64, c_int64_p]),
     "vbnmf_matrix_import_layout": (ctypes.c_int, [_VP, _VP, _I64]),
     "vbnmf_device_sweep_workgroups": (ctypes.c_int, [_I32, c_int32_p]),

@@ -221,6 +221,10 @@ struct vbnmf_matrix {
     // sum over stored entries of -x log x + x, formed once (whole matrix; ML-NMF likelihood constant)
     mutable std::once_flag xlx_once;
     mutable double xlx = 0.0;
+    // vbnmf_matrix_prepare_async: the cell order and the row-major copy being formed on a background host thread
+    mutable std::mutex prep_mu;
+    mutable std::thread prep;
+    ~vbnmf_matrix() { if (prep.joinable()) prep.join(); }
 };
 namespace vbnmf {
 // The layout of `side` for the whole matrix at the default geometry of padded rank R: from the matrix's cache, or

@@ -197,7 +197,7 @@ void free_side(DeviceSide &S)
 }
 
 // Device copy of a layout's arrays; `X` != null: the layout is (possibly) cached on the matrix and so is its copy.
-int upload_side(const Layout &L, int R, int device, const vbnmf_matrix *X, DeviceSide &S)
+int upload_side(const Layout &L, int R, int device, const vbnmf_matrix *X, DeviceSide &S, bool with_part = true)
 {
     S.n_major = L.n_major; S.n_minor = L.n_minor; S.n_tasks = L.n_tasks; S.n_slices = L.n_slices;
     S.n_slots = L.n_slots; S.block_width = L.block_width; S.n_blocks = L.n_blocks; S.n_wg = L.n_wg; S.wide = L.wide;
@@ -234,7 +234,7 @@ int upload_side(const Layout &L, int R, int device, const vbnmf_matrix *X, Devic
     S.packed = A->packed; S.widx = A->widx; S.wval = A->wval; S.task_major = A->task_major; S.inv_task = A->inv_task;
     S.slice_width = A->slice_width; S.seg_block = A->seg_block; S.seg_ptr = A->seg_ptr; S.wg_seg0 = A->wg_seg0;
     S.inv_ptr = A->inv_ptr; S.slice_off = A->slice_off; S.slice_fast = A->slice_fast; S.block_start = A->block_start;
-    if (int rc = dev_alloc(&S.part, (size_t)L.n_slices * kLanes * R)) return rc;
+    if (with_part) { if (int rc = dev_alloc(&S.part, (size_t)L.n_slices * kLanes * R)) return rc; }
     return VBNMF_OK;
 }
 
@@ -833,6 +833,29 @@ int vbnmf_engine_create_part(const vbnmf_matrix *X, int64_t cb, int64_t ce, int6
                              int32_t device, vbnmf_engine **out)
 {
     return vbnmf_engine_create_geom(X, cb, ce, m_global, r, 0, device, out);
+}
+
+int vbnmf_matrix_preload_layout(const vbnmf_matrix *X, int32_t side, int32_t geometry_rank, int32_t n_wg, int32_t device)
+{
+    if (!X) return fail(VBNMF_ERR_BAD_ARG, "matrix handle is NULL");
+    if (side != 0 && side != 1) return fail(VBNMF_ERR_BAD_ARG, "side must be 0 or 1");
+    if (geometry_rank < 1 || geometry_rank > VBNMF_MAX_RANK || n_wg < 1) return fail(VBNMF_ERR_BAD_ARG, "bad geometry");
+    if (int rc = check_device(device)) return rc;
+    HIPCHECK(hipSetDevice(device));
+    const int R = padded_rank(geometry_rank);
+    const int64_t nmaj = side == 0 ? X->M.n : X->M.m, nmin = side == 0 ? X->M.m : X->M.n;
+    int rc = VBNMF_OK;
+    try {
+        const LayoutParams lp = default_layout_params(nmaj, nmin, R, n_wg, X->M.nnz);
+        std::shared_ptr<const Layout> L = shared_layout(X, side, lp, rc);
+        if (rc) return rc;
+        DeviceSide S;                                // the shared arrays stay in the matrix's cache; the per-engine part goes
+        rc = upload_side(*L, R, device, X, S, false);
+        free_side(S);
+    } catch (const std::bad_alloc &) {
+        rc = fail(VBNMF_ERR_OOM, "out of host memory building the tiled layout");
+    }
+    return rc;
 }
 
 int vbnmf_device_sweep_workgroups(int32_t device, int32_t *n_wg)

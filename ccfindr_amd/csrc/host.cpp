@@ -1300,6 +1300,43 @@ int vbnmf_matrix_shell(const double *meta, vbnmf_matrix **out)
 
 int vbnmf_matrix_is_shell(const vbnmf_matrix *X) { return X && X->M.shell ? 1 : 0; }
 
+// The per-matrix work every whole-matrix layout starts from, done ahead of need (e.g. on a second host thread while the
+// cell side is being cut): the order of the cells (order.cpp) and the row-major copy the gene side is cut from.
+// The same on a background host thread owned by the handle (joined by vbnmf_matrix_prepare and by destroy): the call
+// returns at once, and whoever needs the order or the row-major copy first simply waits for it (std::call_once).
+int vbnmf_matrix_prepare_async(const vbnmf_matrix *X)
+{
+    if (!X) return fail(VBNMF_ERR_BAD_ARG, "matrix handle is NULL");
+    if (X->M.shell) return VBNMF_OK;
+    std::lock_guard<std::mutex> g(X->prep_mu);
+    if (X->prep.joinable()) return VBNMF_OK;                     // already under way (or done, not yet joined)
+    try {
+        X->prep = std::thread([X] {
+            try { (void)X->M.cell_order(); (void)X->M.row_major(); } catch (...) { /* the consumer that needs them reports the failure */ }
+        });
+    } catch (const std::system_error &) {
+        return fail(VBNMF_ERR_OOM, "could not start the background thread");
+    }
+    return VBNMF_OK;
+}
+
+int vbnmf_matrix_prepare(const vbnmf_matrix *X)
+{
+    if (!X) return fail(VBNMF_ERR_BAD_ARG, "matrix handle is NULL");
+    if (X->M.shell) return VBNMF_OK;
+    {
+        std::lock_guard<std::mutex> g(X->prep_mu);
+        if (X->prep.joinable()) X->prep.join();
+    }
+    try {
+        (void)X->M.cell_order();
+        (void)X->M.row_major();
+    } catch (const std::bad_alloc &) {
+        return fail(VBNMF_ERR_OOM, "out of host memory preparing the matrix");
+    }
+    return VBNMF_OK;
+}
+
 // Blob of the whole-matrix layout of `side` in the geometry of rank `geometry_rank` for engines with n_wg sweep
 // workgroups (vbnmf_device_sweep_workgroups).  buf == NULL: builds (and caches) the layout and returns its blob size in
 // *bytes; otherwise writes the blob (all host threads) into buf[0..capacity).

@@ -77,7 +77,10 @@ std::vector<int32_t> compute_cell_order(const Matrix &X, int64_t cb, int64_t ce)
     // (gene, block) pair to be EMPTY sometimes (at 75 % density every pair is taken whatever the order)
     const int64_t stored = X.colptr[ce] - X.colptr[cb];
     if (mode == 0 || m < 64 || (mode < 0 && (m < 8192 || (double)stored > 0.25 * (double)n * (double)m))) return {};
-    const int K = (int)std::min<int64_t>(kMaxK, std::max<int64_t>(2, m / 256));
+    int K = (int)std::min<int64_t>(kMaxK, std::max<int64_t>(2, m / 256));
+    int rounds = kRounds;
+    if (const char *sv = getenv("VBNMF_ORDER_K")) { const int v = atoi(sv); if (v >= 2 && v <= 256) K = (int)std::min<int64_t>(v, std::max<int64_t>(2, m / 8)); }   // experiments
+    if (const char *sv = getenv("VBNMF_ORDER_ROUNDS")) { const int v = atoi(sv); if (v >= 1 && v <= 100) rounds = v; }
 
     // 1. sketches
     std::vector<uint8_t> group(n);
@@ -134,7 +137,7 @@ std::vector<int32_t> compute_cell_order(const Matrix &X, int64_t cb, int64_t ce)
             }
         });
     };
-    for (int round = 0; round < kRounds; round++) {
+    for (int round = 0; round < rounds; round++) {
         assign(true);
         for (int k = 0; k < K; k++) {
             float acc[kD] = {};

@@ -138,6 +138,18 @@ class CountMatrix:
     def is_shell(self):
         return bool(self._lib.vbnmf_matrix_is_shell(self._h))
 
+    def prepare_async(self):
+        """The same on a background host thread of the library (returns at once)."""
+        N.check(self._lib.vbnmf_matrix_prepare_async(self._h))
+
+    def preload_layout(self, side, geometry_rank, n_wg, device=0):
+        """Uploads that whole-matrix layout to the device ahead of the first engine (the engines share the resident copy)."""
+        N.check(self._lib.vbnmf_matrix_preload_layout(self._h, int(side), int(geometry_rank), int(n_wg), int(device)))
+
+    def prepare(self):
+        """Cell order + row-major copy of X ahead of need (thread-safe; a second host thread may run it beside a cut)."""
+        N.check(self._lib.vbnmf_matrix_prepare(self._h))
+
     def layout_blob_size(self, side, geometry_rank, n_wg):
         """Cuts (and caches) the whole-matrix layout of ``side`` in the geometry of ``geometry_rank`` -> blob bytes."""
         nb = ctypes.c_int64()

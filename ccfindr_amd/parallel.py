@@ -94,7 +94,9 @@ def vb_factorize_sharded(mat, ranks=2, nrun=1, verbose=0, initializer="random", 
     another node arrive by tensor broadcast from their owner.  ``timings`` (a dict) receives this process's split of
     the call: ``layout_s`` (cut / export / wait / import), ``units_s``, ``gather_s``.
     """
+    import os
     import time
+    import uuid
     import torch
     import torch.distributed as dist
     from . import node as shm
@@ -112,7 +114,8 @@ def vb_factorize_sharded(mat, ranks=2, nrun=1, verbose=0, initializer="random", 
     if mat is not None:
         X = mat if isinstance(mat, CountMatrix) or not native else CountMatrix(mat)
     # ---- control plane, round 1 (tiny host objects): who holds X, on which node, and what the guards found
-    mine = {"node": shm.node_key(), "holds": X is not None, "meta": None, "empty": (0, 0), "n_wg": 0}
+    mine = {"node": shm.node_key(), "holds": X is not None, "meta": None, "empty": (0, 0), "n_wg": 0,
+            "token": f"{os.getpid()}_{uuid.uuid4().hex[:10]}"}
     if X is not None and native:
         mine["meta"] = [float(v) for v in X.meta()]
         mine["empty"] = (0, 0) if X.is_shell else tuple(X.empty_counts())            # reference R/bayesian.R:244-247
@@ -153,58 +156,84 @@ def vb_factorize_sharded(mat, ranks=2, nrun=1, verbose=0, initializer="random", 
     if timings is not None:
         bundle["unit_times"] = []
     plan_geometry(bundle, geometry_classes)
-    segments = []                                        # everything this process created or mapped
 
-    # ---- the sweep's layouts: cut once per node, by its holders side by side, shared through /dev/shm
+    # ---- the sweep's layouts: cut once per node, by its holders side by side, shared through /dev/shm.
+    # No collective carries them: a segment's name follows from its builder's token (round 1), the builder renames the
+    # finished segment into place and the peers poll for the name -- so a peer imports the cell side while the builder is
+    # still cutting the gene side, and the builder writes one side out (a second host thread) while it cuts the next.
+    detail = {} if timings is not None else None
+    tick = time.perf_counter
+    cleanup = []                                         # segments this process created (unlinked behind the next barrier)
     if native:
+        import threading
         geoms = sorted({geometry_rank_for(r, bundle["classes"]) or int(r) for r in bundle["ranks"]})
-        pieces = [(g, side) for g in geoms for side in (0, 1)]
+        pieces = [(g, side) for g in geoms for side in (1, 0)]          # cell side first: it needs no row-major copy of X
         builder_of = {pc: node_holders[q % len(node_holders)] for q, pc in enumerate(pieces)}
         n_wg = mine["n_wg"]
-        made = {}
-        detail = {} if timings is not None else None
-        tick = time.perf_counter
-        for pc in pieces:
-            if builder_of[pc] != me:
-                continue
-            if world == 1 or len(my_node) == 1:
-                continue                                 # nobody to share with: engine creation cuts (and caches) it
-            t0 = tick()
-            nb = X.layout_blob_size(pc[1], pc[0], n_wg)
-            t1 = tick()
-            seg = shm.Segment.create(shm.fresh_name(f"layout{pc[0]}_{pc[1]}"), nb)
-            segments.append(seg)
-            X.export_layout(pc[1], pc[0], n_wg, seg.map)
-            made[pc] = (seg.name, nb)
-            if detail is not None:
-                detail[f"cut_side{pc[1]}_s"] = t1 - t0
-                detail[f"export_side{pc[1]}_s"] = tick() - t1
-        if world > 1:
-            shared = [None] * world
-            t0 = tick()
-            dist.all_gather_object(shared, made, group=group)                    # control plane, round 2: segment names
-            if detail is not None:
-                detail["wait_for_builders_s"] = tick() - t0
+        sharing = world > 1 and len(my_node) > 1
+        seg_name = lambda b, pc: f"vbnmf_{peers[b]['token']}_g{pc[0]}_s{pc[1]}"
+        failed_name = lambda b: f"vbnmf_{peers[b]['token']}_failed"
+        wait_s = float(os.environ.get("VBNMF_WAIT_TIMEOUT_S", "300") or 300)
+        if sharing and any(b == me for b in builder_of.values()):
+            writers, errors = [], []
+
+            def write_out(pc):
+                try:
+                    t0 = tick()
+                    nb = X.layout_blob_size(pc[1], pc[0], n_wg)                  # (cached by now: the size only)
+                    seg = shm.Segment.create(seg_name(me, pc) + ".part", nb)
+                    cleanup.append(seg)
+                    X.export_layout(pc[1], pc[0], n_wg, seg.map)
+                    seg.publish(seg_name(me, pc))
+                    t1 = tick()
+                    X.preload_layout(pc[1], pc[0], n_wg, device)                 # this process's own device copy, ahead of its first engine
+                    if detail is not None:
+                        detail[f"export_side{pc[1]}_s"] = t1 - t0
+                        detail[f"preload_side{pc[1]}_s"] = tick() - t1
+                except BaseException as exc:                                     # noqa: BLE001 -- reported through the marker
+                    errors.append(exc)
+
+            try:
+                X.prepare_async()                                                # cell order, then the row-major copy, beside the cut of the cell side
+                for pc in pieces:
+                    if builder_of[pc] != me:
+                        continue
+                    t0 = tick()
+                    X.layout_blob_size(pc[1], pc[0], n_wg)                       # cuts (and caches) the layout
+                    if detail is not None:
+                        detail[f"cut_side{pc[1]}_s"] = tick() - t0
+                    th = threading.Thread(target=write_out, args=(pc,))
+                    th.start()
+                    writers.append(th)
+                for th in writers:
+                    th.join()
+                if errors:
+                    raise errors[0]
+            except BaseException as exc:
+                with open(os.path.join(shm.shm_dir(), failed_name(me)), "w") as fh:   # the peers stop polling and raise
+                    fh.write(f"{type(exc).__name__}: {exc}")
+                raise
+        if sharing:
             t0 = tick()
             for pc in pieces:
                 b = builder_of[pc]
-                if b == me or pc not in shared[b]:
+                if b == me:
                     continue
                 if peers[b]["n_wg"] != n_wg:
                     raise RuntimeError(f"process {b} cuts layouts for {peers[b]['n_wg']} workgroups, this device wants {n_wg}")
-                name, nb = shared[b][pc]
-                seg = shm.Segment.open(name)
-                X.import_layout(seg.map, nb)
+                t1 = tick()
+                seg = shm.Segment.wait_open(seg_name(b, pc), wait_s, failed_name(b))
+                t2 = tick()
+                X.import_layout(seg.map, seg.size)
                 seg.close()
+                t3 = tick()
+                X.preload_layout(pc[1], pc[0], n_wg, device)     # upload it now, beside the wait for the next piece
+                if detail is not None:
+                    detail[f"wait_side{pc[1]}_s"] = t2 - t1
+                    detail[f"import_side{pc[1]}_s"] = t3 - t2
+                    detail[f"preload_side{pc[1]}_s"] = tick() - t3
             if detail is not None:
-                detail["import_s"] = tick() - t0
-            t0 = tick()
-            dist.barrier(group=group)                    # every peer holds its copy: the owners unlink
-            if detail is not None:
-                detail["barrier_s"] = tick() - t0
-            for seg in segments:
-                seg.close()
-            segments = []
+                detail["wait_and_import_s"] = tick() - t0
     t_layout = time.perf_counter()
 
     # ---- the result segment of this node: [ew | eh | sdw | sdh] of every unit, written by the unit's owner
@@ -218,8 +247,10 @@ def vb_factorize_sharded(mat, ranks=2, nrun=1, verbose=0, initializer="random", 
         dist.all_gather_object(box, rseg.name if me == leader else None, group=group)
         if me != leader:
             rseg = shm.Segment.open(box[leader])
-        dist.barrier(group=group)
+        dist.barrier(group=group)                        # every process of the node has imported the layouts and mapped the results
         rseg.unlink()                                    # mapped everywhere: the name can go, the memory lives with the mappings
+        for seg in cleanup:
+            seg.close()
         bundle["state_out"] = lambda irun, r: _unit_views(rseg, offsets[tasks.index((irun, int(r)))], n, m, int(r))
 
     # A unit that raises (hyper-parameter Newton failure, a VBNMFError, rank > min(nrow, ncol) ...) must not keep this
@@ -358,7 +389,10 @@ class CellPartitionedEngine:
         if native is None:
             # one process = no exchange: no communicator is built (a box without librccl can still run it) and the
             # engine, unpartitioned, drives its own loop
-            native = (not injected) and self.world > 1 and dist.get_backend(group) == "nccl"
+            # (VBNMF_RCCL_LIB names a stand-in for librccl that accepts several ranks on one device -- tests/fake_rccl --, so a
+            # gloo rehearsal on one GPU can still run the library's own collective and its device-driven loop)
+            import os
+            native = (not injected) and self.world > 1 and (dist.get_backend(group) == "nccl" or bool(os.environ.get("VBNMF_RCCL_LIB")))
         self.native = bool(native)
         self.comm = None
         if self.native:

@@ -126,6 +126,17 @@ void vbnmf_matrix_destroy(vbnmf_matrix *X);
 int vbnmf_matrix_get_meta(const vbnmf_matrix *X, double *meta);
 int vbnmf_matrix_shell(const double *meta, vbnmf_matrix **out);
 int vbnmf_matrix_is_shell(const vbnmf_matrix *X);
+/* The per-matrix work every whole-matrix layout starts from, ahead of need and safe to call from a second host thread
+ * while a layout is being cut: the internal order of the cells and the row-major copy of X (the gene side's input). */
+int vbnmf_matrix_prepare(const vbnmf_matrix *X);
+/* The same, started on a background host thread the handle owns: returns at once.  Meant for the caller that ingests X
+ * for whole-matrix factorisations (vb_factorize, a rank sweep) and has other set-up to do before the first engine. */
+int vbnmf_matrix_prepare_async(const vbnmf_matrix *X);
+/* Uploads the whole-matrix layout of `side` (geometry_rank, n_wg as for vbnmf_matrix_export_layout; cut now if it is not
+ * cached or imported yet) to HIP device `device` ahead of the first engine: engines created afterwards in that geometry
+ * on that device share the resident copy (they always do among themselves; this only moves the upload earlier, e.g.
+ * beside the wait for the other side's layout). */
+int vbnmf_matrix_preload_layout(const vbnmf_matrix *X, int32_t side, int32_t geometry_rank, int32_t n_wg, int32_t device);
 int vbnmf_matrix_export_layout(const vbnmf_matrix *X, int32_t side, int32_t geometry_rank, int32_t n_wg,
                                void *buf, int64_t capacity, int64_t *bytes);
 int vbnmf_matrix_import_layout(const vbnmf_matrix *X, const void *buf, int64_t bytes);

@@ -40,6 +40,7 @@ def worker(rank, world, port, path, q):
             t0 = time.perf_counter()
             M = C.CountMatrix(X)
             t_ingest = time.perf_counter() - t0
+            M.prepare_async()                # ingested for whole-matrix factorisations: the second orientation forms in the background
         # time the device-driven loops of this process's units
         stepping = {"s": 0.0, "units": []}
         orig = C.VBEngine.run

@@ -37,7 +37,10 @@ def test_bare_launch_composes_the_torchrun_command(monkeypatch):
 
 @pytest.mark.gpu
 def test_bare_launch_two_ranks_on_one_gpu_prints_one_json_line():
-    env = dict(os.environ, BENCH_BACKEND="gloo", BENCH_ONE_DEVICE="1")
+    fake = os.path.join(ROOT, "tests", "fake_rccl", "_build", "libfake_rccl.so")
+    assert os.path.exists(fake)
+    # two ranks on the ONE test GPU: gloo for torch.distributed, the librccl stand-in for the library's own collective
+    env = dict(os.environ, BENCH_BACKEND="gloo", BENCH_ONE_DEVICE="1", VBNMF_RCCL_LIB=fake)
     env.pop("WORLD_SIZE", None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--small", "--steps", "5", "--warmup", "2",
                         "--no-cpu", "--no-ml"], env=env, capture_output=True, text=True, timeout=900)
@@ -47,3 +50,13 @@ def test_bare_launch_two_ranks_on_one_gpu_prints_one_json_line():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 5 and out["value"] > 0
     assert "value_host_stepped" in out and out["warmup_effective"] >= 2 and "setup" in out
+    # config C4 and C5 ride in the same line (VERDICT r03 Next #3)
+    sweep = out["rank_sweep"]
+    assert "error" not in sweep, sweep
+    assert sweep["wall_s"] > 0 and sweep["iterations_by_rank"] and set(sweep["iterations_by_rank"]) <= {str(r) for r in range(2, 7)}
+    assert len(sweep["per_process"]) == 2 and all(q["stepping_s"] > 0 and q["setup_s"] > 0 for q in sweep["per_process"])
+    assert sorted(r for q in sweep["per_process"] for r in q["ranks"]) == list(range(2, 7))
+    cells = out["cells_partitioned"]
+    assert "error" not in cells, cells
+    assert cells["value"] > 0 and cells["allreduce_ms"] > 0 and "device-driven" in cells["loop"]
+    assert 0 < cells["roofline"]["hbm"]["frac"] < 1 and 0 < cells["roofline"]["fp64"]["frac"] < 1
