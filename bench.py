@@ -513,7 +513,7 @@ def main():
         achieved = bytes_sweep / sweep_s / 1e9 if sweep_cnt else None
         info = base_eng.layout_info()
         traffic, traffic_source = None, None
-        for tname in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):          # newest rocprofv3 --pmc summary kept under profiles/
+        for tname in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):          # newest rocprofv3 --pmc summary kept under profiles/
             tpath = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tpath) and not args.small and args.rank in (0, 10):
                 try:

@@ -79,6 +79,7 @@ SIGNATURES = {
     "vbnmf_matrix_export_layout": (ctypes.c_int, [_VP, _I32, _I32, _I32, _VP, _I64, c_int64_p]),
     "vbnmf_matrix_import_layout": (ctypes.c_int, [_VP, _VP, _I64]),
     "vbnmf_device_sweep_workgroups": (ctypes.c_int, [_I32, c_int32_p]),
+    "vbnmf_device_warmup": (ctypes.c_int, [_I32]),
     "vbnmf_matrix_destroy": (None, [_VP]),
     "vbnmf_engine_create": (ctypes.c_int, [_VP, _I32, _I32, _VPP]),
     "vbnmf_engine_create_part": (ctypes.c_int, [_VP, _I64, _I64, _I64, _I32, _I32, _VPP]),

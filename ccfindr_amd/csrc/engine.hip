@@ -43,7 +43,8 @@ using namespace vbnmf;
 
 namespace {
 
-constexpr int kHostOut = 16;          // doubles in the pinned result block of an engine
+constexpr int kHostOut = 16;
+void dev_free(void *p);             // returns a device buffer to the pool (below)          // doubles in the pinned result block of an engine
 
 // The layout's arrays on the device.  Engines made from a cached layout (same matrix, same geometry, same device)
 // share one of these; the per-engine part is DeviceSide::part.
@@ -59,9 +60,9 @@ struct DeviceArrays {
         int cur = -1;
         (void)hipGetDevice(&cur);
         (void)hipSetDevice(device);
-        (void)hipFree(packed); (void)hipFree(widx); (void)hipFree(wval); (void)hipFree(task_major); (void)hipFree(inv_task);
-        (void)hipFree(slice_width); (void)hipFree(seg_block); (void)hipFree(seg_ptr); (void)hipFree(wg_seg0); (void)hipFree(inv_ptr);
-        (void)hipFree(slice_off); (void)hipFree(slice_fast); (void)hipFree(block_start);
+        dev_free(packed); dev_free(widx); dev_free(wval); dev_free(task_major); dev_free(inv_task);
+        dev_free(slice_width); dev_free(seg_block); dev_free(seg_ptr); dev_free(wg_seg0); dev_free(inv_ptr);
+        dev_free(slice_off); dev_free(slice_fast); dev_free(block_start);
         if (cur >= 0) (void)hipSetDevice(cur);
     }
 };
@@ -79,15 +80,91 @@ struct DeviceSide {
     bool wide = false;
 };
 
+// ---- device buffer pool.  An engine owns ~25 device buffers (state, partial rows up to 100 MB a side, reduce buffers);
+// a rank sweep creates and destroys an engine per (run, rank) unit, and every hipFree synchronises the whole device --
+// including the streams of other engines of the process (vb_factorize(concurrent = K)).  Freed buffers therefore go to a
+// per-process free list and the next engine takes the smallest one that fits (within 1.5 x of the request); the list holds
+// at most VBNMF_POOL_MB (default 4096) and gives the oldest buffers back to the driver beyond that.  Measured on the C4
+// sweep (19 engines in a row): engine creation + destruction 0.5 s -> 0.1 s (profiles/r04_c4_sweep.json).
+struct PoolBuf { void *p; size_t bytes; int device; };
+struct DevicePool {
+    std::mutex mu;
+    std::vector<PoolBuf> free_list;                  // oldest first
+    std::vector<PoolBuf> live;                       // buffers handed out (size and device of every pointer)
+    size_t held = 0;
+    size_t cap = [] { const char *s = getenv("VBNMF_POOL_MB"); long v = s ? atol(s) : 4096; return (size_t)(v < 0 ? 0 : v) << 20; }();
+};
+DevicePool &device_pool() { static DevicePool *P = new DevicePool(); return *P; }      // (never destroyed: no HIP calls at exit)
+
+int pool_alloc(void **p, size_t bytes)
+{
+    *p = nullptr;
+    if (bytes == 0) bytes = 8;
+    int device = 0;
+    (void)hipGetDevice(&device);
+    DevicePool &P = device_pool();
+    {
+        std::lock_guard<std::mutex> g(P.mu);
+        int best = -1;
+        for (int q = 0; q < (int)P.free_list.size(); q++) {
+            const PoolBuf &b = P.free_list[q];
+            if (b.device == device && b.bytes >= bytes && b.bytes <= bytes + bytes / 2 + 4096 && (best < 0 || b.bytes < P.free_list[best].bytes)) best = q;
+        }
+        if (best >= 0) {
+            PoolBuf b = P.free_list[best];
+            P.free_list.erase(P.free_list.begin() + best);
+            P.held -= b.bytes;
+            P.live.push_back(b);
+            *p = b.p;
+            return VBNMF_OK;
+        }
+    }
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipErrorOutOfMemory) {                  // give the pooled buffers back and try once more
+        (void)hipGetLastError();
+        std::vector<PoolBuf> drop;
+        { std::lock_guard<std::mutex> g(P.mu); drop.swap(P.free_list); P.held = 0; }
+        for (const PoolBuf &b : drop) (void)hipFree(b.p);
+        e = hipMalloc(p, bytes);
+    }
+    if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); return fail(VBNMF_ERR_OOM, "out of device memory (%zu bytes)", bytes); }
+    if (e != hipSuccess) return fail(VBNMF_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(e));
+    std::lock_guard<std::mutex> g(P.mu);
+    P.live.push_back({*p, bytes, device});
+    return VBNMF_OK;
+}
+
+// The caller guarantees that no queued work still uses the buffer (engines synchronise their streams before they free).
+void dev_free(void *p)
+{
+    if (!p) return;
+    DevicePool &P = device_pool();
+    std::vector<PoolBuf> drop;
+    {
+        std::lock_guard<std::mutex> g(P.mu);
+        PoolBuf b{p, 0, 0};
+        bool known = false;
+        for (size_t q = 0; q < P.live.size(); q++)
+            if (P.live[q].p == p) { b = P.live[q]; P.live.erase(P.live.begin() + q); known = true; break; }
+        if (!known || P.cap == 0 || b.bytes > P.cap) { drop.push_back(b); }
+        else {
+            P.free_list.push_back(b);
+            P.held += b.bytes;
+            while (P.held > P.cap && !P.free_list.empty()) {
+                drop.push_back(P.free_list.front());
+                P.held -= P.free_list.front().bytes;
+                P.free_list.erase(P.free_list.begin());
+            }
+        }
+    }
+    for (const PoolBuf &b : drop) (void)hipFree(b.p);
+}
+
 template <typename T>
 int dev_alloc(T **p, size_t count)
 {
-    *p = nullptr;
     if (count == 0) count = 1;
-    hipError_t e = hipMalloc((void **)p, count * sizeof(T));
-    if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); return fail(VBNMF_ERR_OOM, "out of device memory (%zu bytes)", count * sizeof(T)); }
-    if (e != hipSuccess) return fail(VBNMF_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(e));
-    return VBNMF_OK;
+    return pool_alloc((void **)p, count * sizeof(T));
 }
 
 template <typename T, typename A>
@@ -159,6 +236,8 @@ struct vbnmf_engine {
     double *d_out = nullptr;          // [8]
     double *h_out = nullptr;          // pinned, device-visible [kHostOut]; [7] = sequence flag; [8..12] = hyper, lk0 of a device-driven loop
     double *h_out_dev = nullptr;      // device address of h_out
+    double *h_stage = nullptr;        // pinned staging of set_state / get_state (index-major copies of the state arrays)
+    size_t h_stage_count = 0;
     double *h_hist = nullptr;         // pinned, device-visible per-step history of the device-driven loops (grown on demand)
     double *h_hist_dev = nullptr;
     size_t h_hist_count = 0;
@@ -190,9 +269,57 @@ struct vbnmf_engine {
 
 namespace {
 
+// Pinned staging buffer of an engine's state transfers (true asynchronous DMA instead of the runtime's bounce through its
+// own staging for pageable memory).  Engines hand theirs on through a small per-process list when they are destroyed.
+struct StagePool { std::mutex mu; std::vector<std::pair<double *, size_t>> free_list; };
+StagePool &stage_pool() { static StagePool *P = new StagePool(); return *P; }
+
+int ensure_stage(vbnmf_engine *e, size_t count)
+{
+    if (count <= e->h_stage_count) return VBNMF_OK;
+    StagePool &P = stage_pool();
+    {
+        std::lock_guard<std::mutex> g(P.mu);
+        if (e->h_stage) { P.free_list.emplace_back(e->h_stage, e->h_stage_count); e->h_stage = nullptr; e->h_stage_count = 0; }
+        int best = -1;
+        for (int q = 0; q < (int)P.free_list.size(); q++)
+            if (P.free_list[q].second >= count && (best < 0 || P.free_list[q].second < P.free_list[best].second)) best = q;
+        if (best >= 0) {
+            e->h_stage = P.free_list[best].first; e->h_stage_count = P.free_list[best].second;
+            P.free_list.erase(P.free_list.begin() + best);
+            return VBNMF_OK;
+        }
+    }
+    double *p = nullptr;
+    hipError_t he = hipHostMalloc((void **)&p, count * sizeof(double), hipHostMallocDefault);
+    if (he != hipSuccess) { (void)hipGetLastError(); return fail(VBNMF_ERR_OOM, "pinned staging buffer (%zu bytes): %s", count * sizeof(double), hipGetErrorString(he)); }
+    e->h_stage = p; e->h_stage_count = count;
+    return VBNMF_OK;
+}
+
+void release_stage(vbnmf_engine *e)
+{
+    if (!e->h_stage) return;
+    StagePool &P = stage_pool();
+    std::vector<std::pair<double *, size_t>> drop;
+    {
+        std::lock_guard<std::mutex> g(P.mu);
+        P.free_list.emplace_back(e->h_stage, e->h_stage_count);
+        size_t held = 0;
+        for (auto &b : P.free_list) held += b.second * sizeof(double);
+        while (P.free_list.size() > 8 || held > ((size_t)1 << 30)) {           // at most 8 buffers / 1 GiB kept
+            held -= P.free_list.front().second * sizeof(double);
+            drop.push_back(P.free_list.front());
+            P.free_list.erase(P.free_list.begin());
+        }
+    }
+    for (auto &b : drop) (void)hipHostFree(b.first);
+    e->h_stage = nullptr; e->h_stage_count = 0;
+}
+
 void free_side(DeviceSide &S)
 {
-    (void)hipFree(S.part);
+    dev_free(S.part);
     S = DeviceSide();                          // drops this engine's reference to the (shared) layout arrays
 }
 
@@ -689,14 +816,15 @@ void vbnmf_engine_destroy(vbnmf_engine *e)
         e->comm->tables_ready = false;
     }
     free_side(e->A); free_side(e->B);
-    (void)hipFree(e->lw); (void)hipFree(e->llw); (void)hipFree(e->ew); (void)hipFree(e->dw);
-    (void)hipFree(e->lh); (void)hipFree(e->llh); (void)hipFree(e->eh); (void)hipFree(e->dh);
-    (void)hipFree(e->epart); (void)hipFree(e->bpW); (void)hipFree(e->bpH);
-    (void)hipFree(e->d_perm); (void)hipFree(e->d_ids[0]); (void)hipFree(e->d_ids[1]); (void)hipFree(e->d_table); (void)hipFree(e->svd_ws); (void)hipFree(e->svd_status);
-    (void)hipFree(e->red); (void)hipFree(e->red_g); (void)hipFree(e->d_out);
+    dev_free(e->lw); dev_free(e->llw); dev_free(e->ew); dev_free(e->dw);
+    dev_free(e->lh); dev_free(e->llh); dev_free(e->eh); dev_free(e->dh);
+    dev_free(e->epart); dev_free(e->bpW); dev_free(e->bpH);
+    dev_free(e->d_perm); dev_free(e->d_ids[0]); dev_free(e->d_ids[1]); dev_free(e->d_table); dev_free(e->svd_ws); dev_free(e->svd_status);
+    dev_free(e->red); dev_free(e->red_g); dev_free(e->d_out);
     for (hipEvent_t ev : e->ev_ring) (void)hipEventDestroy(ev);
-    if (e->cstream) (void)hipStreamDestroy(e->cstream); (void)hipFree(e->dbg); (void)hipFree(e->logtab); (void)hipFree(e->ctl);
-    (void)hipFree(e->ctl2); (void)hipFree(e->bpW_alt); (void)hipFree(e->bpH_alt);
+    if (e->cstream) (void)hipStreamDestroy(e->cstream); dev_free(e->dbg); dev_free(e->logtab); dev_free(e->ctl);
+    dev_free(e->ctl2); dev_free(e->bpW_alt); dev_free(e->bpH_alt);
+    release_stage(e);
     if (e->h_out) (void)hipHostFree(e->h_out);
     if (e->h_hist) (void)hipHostFree(e->h_hist);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
@@ -858,6 +986,27 @@ int vbnmf_matrix_preload_layout(const vbnmf_matrix *X, int32_t side, int32_t geo
     return rc;
 }
 
+// First use of a device by this process, ahead of need: the HIP context, the first allocation and the load of the
+// library's code object cost ~0.15 s the first time and nothing afterwards.  A process that has to wait for something else
+// first (a sharded sweep's peers waiting for the layouts) spends that wait here.
+int vbnmf_device_warmup(int32_t device)
+{
+    if (int rc = check_device(device)) return rc;
+    HIPCHECK(hipSetDevice(device));
+    double *p = nullptr;
+    if (int rc = dev_alloc(&p, 1024)) return rc;
+    double host[8] = {0};
+    hipError_t he = hipMemcpy(p, host, sizeof host, hipMemcpyHostToDevice);
+    if (he == hipSuccess) {
+        hipLaunchKernelGGL(k_test_special, dim3(1), dim3(64), 0, nullptr, 3, (int64_t)0, (const double *)p, p, (const LogTabEntry *)nullptr);   // n = 0: loads the module, touches nothing
+        he = hipGetLastError();
+    }
+    if (he == hipSuccess) he = hipDeviceSynchronize();
+    dev_free(p);
+    if (he != hipSuccess) return fail(VBNMF_ERR_HIP, "device warm-up failed: %s", hipGetErrorString(he));
+    return VBNMF_OK;
+}
+
 int vbnmf_device_sweep_workgroups(int32_t device, int32_t *n_wg)
 {
     if (!n_wg) return fail(VBNMF_ERR_BAD_ARG, "NULL argument");
@@ -902,21 +1051,28 @@ int vbnmf_engine_set_stream(vbnmf_engine *e, void *stream)
 
 // column-major n x r (R matrix) -> device [n][R]; or r x m column-major (already index-major) -> [m][R].
 // perm (cell-indexed arrays only): device row p holds the caller's major perm[p] (the layout's order of the cells).
-static void to_index_major(const double *src, int64_t nmaj, int r, int R, bool src_is_major_contiguous, std::vector<double> &dst,
+static void to_index_major(const double *src, int64_t nmaj, int r, int R, bool src_is_major_contiguous, double *dst,
                            const std::vector<int32_t> *perm = nullptr)
 {
-    dst.assign((size_t)nmaj * R, 0.0);
     const int32_t *pm = (perm && !perm->empty()) ? perm->data() : nullptr;
     parallel_for(nmaj, [&](int64_t b, int64_t e, int) {
         for (int64_t M = b; M < e; M++) {
             const int64_t S = pm ? pm[M] : M;
-            for (int k = 0; k < r; k++)
-                dst[(size_t)M * R + k] = src_is_major_contiguous ? src[(size_t)S * r + k] : src[S + (size_t)k * nmaj];
+            double *d = dst + (size_t)M * R;
+            for (int k = 0; k < r; k++) d[k] = src_is_major_contiguous ? src[(size_t)S * r + k] : src[S + (size_t)k * nmaj];
+            for (int k = r; k < R; k++) d[k] = 0.0;
         }
     });
 }
 
-static void from_index_major(const std::vector<double> &src, int64_t nmaj, int r, int R, bool dst_is_major_contiguous, double *dst,
+static void to_index_major(const double *src, int64_t nmaj, int r, int R, bool src_is_major_contiguous, std::vector<double> &dst,
+                           const std::vector<int32_t> *perm = nullptr)
+{
+    dst.resize((size_t)nmaj * R);
+    to_index_major(src, nmaj, r, R, src_is_major_contiguous, dst.data(), perm);
+}
+
+static void from_index_major(const double *src, int64_t nmaj, int r, int R, bool dst_is_major_contiguous, double *dst,
                              const std::vector<int32_t> *perm = nullptr)
 {
     const int32_t *pm = (perm && !perm->empty()) ? perm->data() : nullptr;
@@ -931,25 +1087,30 @@ static void from_index_major(const std::vector<double> &src, int64_t nmaj, int r
     });
 }
 
+static void from_index_major(const std::vector<double> &src, int64_t nmaj, int r, int R, bool dst_is_major_contiguous, double *dst,
+                             const std::vector<int32_t> *perm = nullptr)
+{
+    from_index_major(src.data(), nmaj, r, R, dst_is_major_contiguous, dst, perm);
+}
+
 int vbnmf_engine_set_state(vbnmf_engine *e, const double *lw, const double *lh, const double *eh)
 {
     if (!e || !lw || !lh || !eh) return fail(VBNMF_ERR_BAD_ARG, "NULL argument");
     if (int rc = use_device(e)) return rc;
     e->has_state = false; e->stats_ready = false; e->step_pending = false; e->prime_pending = false;
     e->ml_ready = false;
-    try {
-        std::vector<double> tmp;
-        to_index_major(lw, e->n, e->r, e->R, false, tmp);
-        HIPCHECK(hipMemcpyAsync(e->lw, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
-        HIPCHECK(hipStreamSynchronize(e->stream));
-        to_index_major(lh, e->m, e->r, e->R, true, tmp, &e->cell_perm);
-        HIPCHECK(hipMemcpyAsync(e->lh, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
-        HIPCHECK(hipStreamSynchronize(e->stream));
-        to_index_major(eh, e->m, e->r, e->R, true, tmp, &e->cell_perm);
-        HIPCHECK(hipMemcpyAsync(e->eh, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
-        HIPCHECK(hipStreamSynchronize(e->stream));
-    } catch (const std::bad_alloc &) {
-        return fail(VBNMF_ERR_OOM, "out of host memory staging the state");
+    {
+        // the three arrays in index-major form in ONE pinned staging buffer, three asynchronous copies, one wait
+        const size_t nR = (size_t)e->n * e->R, mR = (size_t)e->m * e->R;
+        if (int rc = ensure_stage(e, nR + 2 * mR)) return rc;
+        double *s_lw = e->h_stage, *s_lh = s_lw + nR, *s_eh = s_lh + mR;
+        to_index_major(lw, e->n, e->r, e->R, false, s_lw);
+        HIPCHECK(hipMemcpyAsync(e->lw, s_lw, nR * sizeof(double), hipMemcpyHostToDevice, e->stream));
+        to_index_major(lh, e->m, e->r, e->R, true, s_lh, &e->cell_perm);
+        HIPCHECK(hipMemcpyAsync(e->lh, s_lh, mR * sizeof(double), hipMemcpyHostToDevice, e->stream));
+        to_index_major(eh, e->m, e->r, e->R, true, s_eh, &e->cell_perm);
+        HIPCHECK(hipMemcpyAsync(e->eh, s_eh, mR * sizeof(double), hipMemcpyHostToDevice, e->stream));
+        // (prime_state's kernels follow on the same stream; its closing synchronise also covers the staging buffer)
     }
     return prime_state(e);
 }
@@ -1060,12 +1221,12 @@ int ensure_history(vbnmf_engine *e, size_t doubles)
 }
 
 // What a partitioned engine needs beside its own stream: the stream the all-reduces go on, the receive buffer, and
-// a ring of events (three per step, steps queued at most two batches ahead: 96 never wraps onto a pending one).
+// a ring of events (four per step, steps queued at most three batches of eight ahead: 160 never wraps onto a pending one).
 int ensure_comm_resources(vbnmf_engine *e)
 {
     if (!e->cstream) HIPCHECK(hipStreamCreateWithFlags(&e->cstream, hipStreamNonBlocking));
     if (!e->red_g) { if (int rc = dev_alloc(&e->red_g, (size_t)e->red_count)) return rc; }
-    while (e->ev_ring.size() < 96) {
+    while (e->ev_ring.size() < 160) {
         hipEvent_t ev;
         HIPCHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         e->ev_ring.push_back(ev);
@@ -1122,7 +1283,7 @@ int group_tables(vbnmf_comm *c)
         const size_t off = (size_t)e->n * e->R + e->R + 2;
         sb[p] = e->red; rb[p] = e->red_g; ss[p] = e->red + off; rs[p] = e->red_g + off;
     }
-    (void)hipFree(c->d_send_big); (void)hipFree(c->d_send_small); (void)hipFree(c->d_recv_big); (void)hipFree(c->d_recv_small);
+    dev_free(c->d_send_big); dev_free(c->d_send_small); dev_free(c->d_recv_big); dev_free(c->d_recv_small);
     c->d_send_big = c->d_send_small = nullptr; c->d_recv_big = c->d_recv_small = nullptr;      // (tables of an earlier membership)
     if (int rc = dev_alloc(&c->d_send_big, (size_t)P)) return rc;
     if (int rc = dev_alloc(&c->d_send_small, (size_t)P)) return rc;
@@ -1138,7 +1299,7 @@ int group_tables(vbnmf_comm *c)
 
 // One step of the device-driven VB loop, queued on every engine of the group.
 //   unpartitioned : k_update(W) k_update(H) k_sweep(both sides) k_control
-//   partitioned   : k_update(W <- reduced statistics) k_update(H) | gene-side sweep, k_pack, k_tail_h | event
+//   partitioned   : k_update(W <- reduced statistics) k_update(H) | gene-side sweep | event -> comm stream: k_pack, k_tail_h
 //                   -> comm stream: all-reduce [swsum | rowSum(eh) | 2 scalars]     (RCCL, or k_group_sum)
 //                   || main stream: cell-side sweep, k_tail_data | event
 //                   -> comm stream: all-reduce [data term | sum lgamma(x+1)] | event -> main stream: k_control
@@ -1192,16 +1353,26 @@ int queue_vb_step(const LoopGroup &G, double fudge, bool hist, int max_it)
         if (!rc) rc = launch_update(e, false, 0, 0, fudge, e->ctl);
         if (!rc) rc = launch_vb_side(e, true);
         if (rc) return rc;
+        // The gene-side partials are packed into the send buffer on the engine's COMM stream, not on the main one: k_pack
+        // (a gather of 100 MB of task rows at C5: 26 us) and k_tail_h hold no LDS and run beside the cell-side sweep, which
+        // does not depend on them -- only the all-reduce does, and it follows them in comm-stream order.
+        static const bool pack_on_main = [] { const char *v = getenv("VBNMF_PACK_ON_MAIN"); return v && v[0] == '1'; }();   // A/B switch
+        hipStream_t ps = pack_on_main ? e->stream : e->cstream;
+        if (!pack_on_main) {
+            hipEvent_t evS = next_event(e);
+            HIPCHECK(hipEventRecord(evS, e->stream));
+            HIPCHECK(hipStreamWaitEvent(e->cstream, evS, 0));
+        }
         const int64_t cnt = e->n * e->R;
-        hipLaunchKernelGGL(k_pack, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, e->stream, e->A.part, e->A.inv_ptr, e->A.inv_task, e->n, e->R, e->red);
+        hipLaunchKernelGGL(k_pack, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ps, e->A.part, e->A.inv_ptr, e->A.inv_task, e->n, e->R, e->red);
         HIPCHECK(hipGetLastError());
-        hipLaunchKernelGGL(k_tail_h, dim3(1), dim3(1024), 0, e->stream, e->bpH, e->ub, e->R, e->red + cnt, &e->ctl->stop);
+        hipLaunchKernelGGL(k_tail_h, dim3(1), dim3(1024), 0, ps, e->bpH, e->ub, e->R, e->red + cnt, &e->ctl->stop);
         HIPCHECK(hipGetLastError());
         evA[p] = next_event(e);
-        HIPCHECK(hipEventRecord(evA[p], e->stream));
+        HIPCHECK(hipEventRecord(evA[p], ps));
     }
     if (c->kind == 0) {
-        HIPCHECK(hipStreamWaitEvent(L->cstream, evA[0], 0));
+        HIPCHECK(hipStreamWaitEvent(L->cstream, evA[0], 0));   // (a no-op when k_pack / k_tail_h ran on the comm stream themselves)
         if (int rc = rccl_check(rccl_api().AllReduce(L->red, L->red_g, (size_t)nbig, ncclDouble, ncclSum, c->nc, L->cstream), "ncclAllReduce")) return rc;
     } else {
         for (int p = 0; p < P; p++) HIPCHECK(hipStreamWaitEvent(L->cstream, evA[p], 0));
@@ -1442,7 +1613,7 @@ void vbnmf_comm_destroy(vbnmf_comm *c)
     if (!c) return;
     for (vbnmf_engine *e : c->members) if (e && e->comm == c) e->comm = nullptr;
     if (c->kind == 0 && c->nc) (void)rccl_api().CommDestroy(c->nc);
-    (void)hipFree(c->d_send_big); (void)hipFree(c->d_send_small); (void)hipFree(c->d_recv_big); (void)hipFree(c->d_recv_small);
+    dev_free(c->d_send_big); dev_free(c->d_send_small); dev_free(c->d_recv_big); dev_free(c->d_recv_small);
     delete c;
 }
 
@@ -1522,7 +1693,7 @@ int vbnmf_group_state_finish(vbnmf_comm *c)
         he = hipGetLastError();
     }
     if (he == hipSuccess) he = hipStreamSynchronize(L->stream);
-    (void)hipFree(d_ptr);
+    dev_free(d_ptr);
     if (he != hipSuccess) return fail(VBNMF_ERR_HIP, "group state exchange failed: %s", hipGetErrorString(he));
     for (int p = 0; p < G.count; p++)
         if (int rc = vbnmf_engine_state_finish(G.e[p])) return rc;
@@ -1545,21 +1716,28 @@ int vbnmf_engine_get_state(vbnmf_engine *e, double *lw, double *lh, double *ew, 
     if (!e) return fail(VBNMF_ERR_BAD_ARG, "engine handle is NULL");
     if (!e->has_state) return fail(VBNMF_ERR_STATE, "get_state before set_state");
     if (int rc = use_device(e)) return rc;
-    HIPCHECK(hipStreamSynchronize(e->stream));
-    try {
-        std::vector<double> tmp;
+    {
         struct Item { double *dst; const double *src; bool gene; };
         const Item items[6] = {{lw, e->lw, true}, {ew, e->ew, true}, {dw, e->dw, true},
                                {lh, e->lh, false}, {eh, e->eh, false}, {dh, e->dh, false}};
-        for (const Item &it : items) {
+        size_t need = 0;
+        for (const Item &it : items) if (it.dst) need += (size_t)(it.gene ? e->n : e->m) * e->R;
+        if (int rc = ensure_stage(e, need)) return rc;
+        size_t off = 0;
+        for (const Item &it : items) {                   // every requested array into the pinned staging buffer, asynchronously ...
+            if (!it.dst) continue;
+            const size_t cnt = (size_t)(it.gene ? e->n : e->m) * e->R;
+            HIPCHECK(hipMemcpyAsync(e->h_stage + off, it.src, cnt * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+            off += cnt;
+        }
+        HIPCHECK(hipStreamSynchronize(e->stream));        // ... one wait (it also covers whatever was queued before) ...
+        off = 0;
+        for (const Item &it : items) {                   // ... then into the caller's column-major arrays
             if (!it.dst) continue;
             const int64_t nmaj = it.gene ? e->n : e->m;
-            tmp.resize((size_t)nmaj * e->R);
-            HIPCHECK(hipMemcpy(tmp.data(), it.src, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
-            from_index_major(tmp, nmaj, e->r, e->R, !it.gene, it.dst, it.gene ? nullptr : &e->cell_perm);
+            from_index_major(e->h_stage + off, nmaj, e->r, e->R, !it.gene, it.dst, it.gene ? nullptr : &e->cell_perm);
+            off += (size_t)nmaj * e->R;
         }
-    } catch (const std::bad_alloc &) {
-        return fail(VBNMF_ERR_OOM, "out of host memory staging the state");
     }
     return VBNMF_OK;
 }
@@ -1809,7 +1987,7 @@ int vbnmf_engine_cluster_ids(vbnmf_engine *e, int32_t *ids)
     if (!e->cell_perm.empty()) { stage.resize((size_t)e->m); host = stage.data(); }      // labels arrive in the layout's cell order
     if (he == hipSuccess) he = hipMemcpyAsync(host, d_ids, (size_t)e->m * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream);
     if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
-    (void)hipFree(d_ids);
+    dev_free(d_ids);
     if (he != hipSuccess) return fail(VBNMF_ERR_HIP, "cluster_ids failed: %s", hipGetErrorString(he));
     if (!e->cell_perm.empty()) for (int64_t p = 0; p < e->m; p++) ids[e->cell_perm[p]] = stage[p];
     return VBNMF_OK;
@@ -2099,8 +2277,8 @@ int vbnmf_test_special_device(int32_t kind, int64_t n, const double *x, double *
     std::vector<LogTabEntry> tab(kLogTabSize);
     fill_log_table(tab.data());
     if (int rc = dev_alloc(&dx, (size_t)n)) return rc;
-    if (int rc = dev_alloc(&dy, (size_t)n)) { (void)hipFree(dx); return rc; }
-    if (int rc = dev_upload(&dt, tab)) { (void)hipFree(dx); (void)hipFree(dy); return rc; }
+    if (int rc = dev_alloc(&dy, (size_t)n)) { dev_free(dx); return rc; }
+    if (int rc = dev_upload(&dt, tab)) { dev_free(dx); dev_free(dy); return rc; }
     int rc = VBNMF_OK;
     hipError_t he = hipMemcpy(dx, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice);
     if (he == hipSuccess && n > 0) {
@@ -2109,7 +2287,7 @@ int vbnmf_test_special_device(int32_t kind, int64_t n, const double *x, double *
     }
     if (he == hipSuccess) he = hipMemcpy(y, dy, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
     if (he != hipSuccess) rc = fail(VBNMF_ERR_HIP, "special-function test kernel failed: %s", hipGetErrorString(he));
-    (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dt);
+    dev_free(dx); dev_free(dy); dev_free(dt);
     return rc;
 }
 

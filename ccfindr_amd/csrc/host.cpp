@@ -793,8 +793,10 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
     // Slices differ in cost by two orders of magnitude and lie sorted by width inside a segment: small chunks
     // handed out through a shared counter, not one contiguous range per thread.
     std::atomic<int64_t> next_chunk{0};
-    const int64_t kChunk = 16;
+    std::atomic<bool> fill_oom{false};                     // a worker thread that runs out of memory says so here (an exception
+    const int64_t kChunk = 16;                             // leaving a std::thread would end the process)
     parallel_for(host_threads(), [&](int64_t, int64_t, int) {
+        try {
         // phase 0 = the task's entries of value 1 (placed first, see above), 1 = those of value 2, 2 = the others
         // (every entry when the fast stretch is off)
         constexpr int NP = 3;
@@ -907,7 +909,12 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
             }
         }
         }
+        } catch (const std::bad_alloc &) {
+            fill_oom.store(true);
+            next_chunk.store(L.n_slices);                  // the other workers stop at their next chunk
+        }
     });
+    if (fill_oom.load()) return fail(VBNMF_ERR_OOM, "out of host memory filling the tiled layout");
     lap("fill");
     return VBNMF_OK;
 }
@@ -1108,13 +1115,17 @@ int vbnmf_matrix_empty_counts(const vbnmf_matrix *X, int64_t *empty_rows, int64_
     // cut in chunks with their own row-sum arrays, added in chunk order (a fixed order: the test for == 0 must not
     // depend on the thread count); 0.15 s single-threaded at the headline size, once per vb_factorize call.
     int T = (int)std::max<int64_t>(1, std::min<int64_t>(64, M.nnz / (1 << 20) + 1));       // chunks: a function of X alone
-    T = (int)std::max<int64_t>(1, std::min<int64_t>(T, ((int64_t)1 << 26) / std::max<int64_t>(1, M.n)));
-    std::vector<std::vector<double>> part(T, std::vector<double>());
+    T = (int)std::max<int64_t>(1, std::min<int64_t>(T, ((int64_t)1 << 24) / std::max<int64_t>(1, M.n)));   // <= 128 MB of row sums in all
+    std::vector<std::vector<double>> part(T);
     std::vector<int64_t> ecs(T, 0);
+    try {                                                   // allocated HERE, not in the worker threads: a bad_alloc there would end in std::terminate
+        for (auto &rs : part) rs.assign(M.n, 0.0);
+    } catch (const std::bad_alloc &) {
+        return fail(VBNMF_ERR_OOM, "out of host memory checking for empty rows (%d x %lld doubles)", T, (long long)M.n);
+    }
     parallel_for(T, [&](int64_t b, int64_t e, int) {
         for (int64_t c = b; c < e; c++) {
             std::vector<double> &rs = part[c];
-            rs.assign(M.n, 0.0);
             for (int64_t j = M.m * c / T; j < M.m * (c + 1) / T; j++) {
                 double cs = 0.0;
                 for (int64_t q = M.colptr[j]; q < M.colptr[j + 1]; q++) { cs += M.val[q]; rs[M.row[q]] += M.val[q]; }

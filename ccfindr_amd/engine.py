@@ -220,6 +220,11 @@ def sweep_workgroups(device=0):
     return v.value
 
 
+def device_warmup(device=0):
+    """First use of the device by this process, ahead of need (vbnmf_device_warmup)."""
+    N.check(N.load().vbnmf_device_warmup(int(device)))
+
+
 class _CudaBuffer:
     """Exposes a raw device pointer through __cuda_array_interface__ (for torch.as_tensor)."""
 

@@ -100,7 +100,7 @@ def vb_factorize_sharded(mat, ranks=2, nrun=1, verbose=0, initializer="random", 
     import torch
     import torch.distributed as dist
     from . import node as shm
-    from .engine import CountMatrix, geometry_rank_for, rank_classes, sweep_workgroups
+    from .engine import CountMatrix, device_warmup, geometry_rank_for, rank_classes, sweep_workgroups
     t_begin = time.perf_counter()
     world, me = 1, 0
     if dist.is_available() and dist.is_initialized():
@@ -121,8 +121,14 @@ def vb_factorize_sharded(mat, ranks=2, nrun=1, verbose=0, initializer="random", 
         mine["empty"] = (0, 0) if X.is_shell else tuple(X.empty_counts())            # reference R/bayesian.R:244-247
     elif X is not None:
         mine["meta"] = [float(v) for v in (X.shape if hasattr(X, "shape") else np.asarray(X).shape)]
+    warm = None
     if native:
-        mine["n_wg"] = sweep_workgroups(device)         # (first HIP call of a fresh process: its runtime start-up runs while the holder cuts)
+        import threading
+        mine["n_wg"] = sweep_workgroups(device)
+        # the device's first use by this process (context, first allocation, code object: ~0.15 s) on a second host thread:
+        # it runs beside the holder's cut, resp. beside this process's wait for the layouts
+        warm = threading.Thread(target=device_warmup, args=(device,))
+        warm.start()
     t_first = time.perf_counter()
     peers = [mine]
     if world > 1:
@@ -234,6 +240,8 @@ def vb_factorize_sharded(mat, ranks=2, nrun=1, verbose=0, initializer="random", 
                     detail[f"preload_side{pc[1]}_s"] = tick() - t3
             if detail is not None:
                 detail["wait_and_import_s"] = tick() - t0
+    if warm is not None:
+        warm.join()
     t_layout = time.perf_counter()
 
     # ---- the result segment of this node: [ew | eh | sdw | sdh] of every unit, written by the unit's owner

@@ -143,6 +143,9 @@ int vbnmf_matrix_import_layout(const vbnmf_matrix *X, const void *buf, int64_t b
 /* Persistent workgroups of the sweep kernels on `device` (one per CU; VBNMF_NWG overrides): the n_wg of the layouts
  * that whole-matrix engines on that device use. */
 int vbnmf_device_sweep_workgroups(int32_t device, int32_t *n_wg);
+/* First use of `device` by this process ahead of need (HIP context, first allocation, load of the library's code object:
+ * ~0.15 s once per process): a process that must wait for something else first spends the wait here. */
+int vbnmf_device_warmup(int32_t device);
 
 /* ---------------------------------------------------------------------------------
  * Engine: device-resident state of one factorisation of (a column block of) X at one

@@ -5,7 +5,7 @@
 #   3. separate --pmc passes (FETCH_SIZE ; WRITE_SIZE ; SQ ; L2) -> gpurun_out/TAG_pmc_*/
 # then profiles/summarize_pmc.py folds 2+3 into profiles-ready files under gpurun_out/TAG_summary/.
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
 REPO=$PWD
 OUT=$REPO/gpurun_out
 mkdir -p $OUT

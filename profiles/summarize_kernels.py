@@ -39,7 +39,7 @@ def main():
     out = os.path.join("gpurun_out", f"{tag}_summary")
     os.makedirs(out, exist_ok=True)
     for name in names:
-        stats = find(f"gpurun_out/{tag}_{name}_stats/**/*kernel_stats.csv")
+        stats = find(f"gpurun_out/{tag}_{name}_stats/**/*kernel_stats.csv") or find(f"gpurun_out/{tag}_{name}_auto_stats/**/*kernel_stats.csv")
         if stats:
             shutil.copy(stats, os.path.join(out, f"{tag}_{name}_kernel_stats.csv"))
         means = {}

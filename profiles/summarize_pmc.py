@@ -2,10 +2,13 @@
 """profiles/summarize_pmc.py TAG -- fold the rocprofv3 outputs of profiles/collect.sh into small files:
 gpurun_out/TAG_summary/{TAG_kernel_stats.csv, TAG_pmc_<pass>.csv (per-kernel means), TAG_traffic.json}.
 HBM bytes per k_sweep launch = 2 x FETCH_SIZE + WRITE_SIZE (both reported in KB; the doubling of FETCH_SIZE is
-the gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md, HBM/rocprofv3 section)."""
+the gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md, HBM/rocprofv3 section: it holds for WIDE COALESCED
+STREAMING reads, 16 B per lane -- the sweep's entry stream).  k_update gathers 8-byte elements row by row: the guide calls
+other access widths uncalibrated, so its bytes are reported AS COUNTED (FETCH_SIZE + WRITE_SIZE), with the doubled figure
+beside it for reference (the counted 49.9 MB already equal the kernel's expected reads at rank 10)."""
 import csv, glob, json, os, sys, collections
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 out = os.path.join("gpurun_out", f"{tag}_summary")
 os.makedirs(out, exist_ok=True)
 
@@ -55,6 +58,8 @@ traffic = {"kernel": "k_sweep", "FETCH_SIZE_KB_per_launch": fs, "WRITE_SIZE_KB_p
                    "note in MI355X_MICROARCH.md prescribes; units KB",
            "k_update_FETCH_SIZE_KB": means.get(("k_update", "FETCH_SIZE")),
            "k_update_WRITE_SIZE_KB": means.get(("k_update", "WRITE_SIZE")),
+           "k_update_hbm_bytes_per_launch_as_counted": ((means.get(("k_update", "FETCH_SIZE")) or 0) + (means.get(("k_update", "WRITE_SIZE")) or 0)) * 1024 or None,
+           "k_update_hbm_bytes_if_fetch_doubled": (2 * (means.get(("k_update", "FETCH_SIZE")) or 0) + (means.get(("k_update", "WRITE_SIZE")) or 0)) * 1024 or None,
            "sq_counters_k_sweep": {c: v for (k, c), v in means.items() if k == "k_sweep" and c.startswith("SQ_")},
            "l2_counters_k_sweep": {c: v for (k, c), v in means.items() if k == "k_sweep" and (c.startswith("TCC") or c.startswith("GRBM"))}}
 json.dump(traffic, open(os.path.join(out, f"{tag}_traffic.json"), "w"), indent=1)

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""profiles/ubench/r04/c5_one_partition.py -- ONE partition of BASELINE config C5 alone on the GPU (30 000 genes x the
+first 25 000 of 200 000 cells, rank 20), as a local group of one: the device-driven partitioned loop exactly as an 8-GPU
+rank runs it (k_update x2, gene-side sweep, k_pack, k_tail_h, the group sum where RCCL's all-reduce goes, cell-side sweep,
+k_tail_data, k_control), with no other partition sharing the chip -- so rocprofv3's per-kernel times are the partition's
+own (profiles/collect_r04_evidence.sh ran all eight partitions side by side: their kernels overlapped).
+    rocprofv3 --kernel-trace --stats ... -- python3 profiles/ubench/r04/c5_one_partition.py [--steps 300]"""
+import argparse, json, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=300)
+    args = ap.parse_args()
+    import torch
+    import bench
+    import ccfindr_amd as C
+    from ccfindr_amd import synth
+    X, n, m, r = bench.make_c5(False)
+    M = C.CountMatrix(X)
+    P = 8
+    cols = (0, m // P)
+    hy = {"aw": 1.0, "bw": 1.0, "ah": 1.0, "bh": 1.0}
+    wh = synth.random_state(n, m, r, hy, seed=1005)
+    comm = C.Communicator.local(1)
+    eng = C.VBEngine(M, r, cols=cols, m_global=m)
+    eng.attach_comm(comm)
+    eng.set_state(wh["lw"], wh["lh"][:, cols[0]:cols[1]], wh["eh"][:, cols[0]:cols[1]])
+    comm.state_finish()
+    comm.run(hy, Itmax=50, Tol=0.0, flags=(False,) * 4)
+    ts = []
+    for _ in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        comm.run(hy, Itmax=args.steps, Tol=0.0, flags=(False,) * 4)
+        torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) / args.steps)
+    info = eng.layout_info()
+    S = X.tocsc()
+    nnz_local = int(S.indptr[cols[1]] - S.indptr[cols[0]])
+    out = {"workload": f"C5 partition 1 of {P}: {n} x {cols[1] - cols[0]} of {m} cells, nnz {nnz_local}, rank {r}, alone on the GPU",
+           "cell_order": os.environ.get("VBNMF_CELL_ORDER", "auto"), "ms_per_step": 1e3 * float(np.median(ts)),
+           "tasks_gene": info["tasks_gene_side"], "tasks_cell": info["tasks_cell_side"]}
+    print(json.dumps(out), flush=True)
+    eng.close(); comm.close(); M.close()
+
+
+if __name__ == "__main__":
+    main()
