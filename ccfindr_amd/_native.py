@@ -78,6 +78,8 @@ SIGNATURES = {
     "vbnmf_matrix_preload_layout": (ctypes.c_int, [_VP, _I32, _I32, _I32, _I32]),
     "vbnmf_matrix_export_layout": (ctypes.c_int, [_VP, _I32, _I32, _I32, _VP, _I64, c_int64_p]),
     "vbnmf_matrix_import_layout": (ctypes.c_int, [_VP, _VP, _I64]),
+    "vbnmf_matrix_share_layout": (ctypes.c_int, [_VP, _I32, _I32, _I32, ctypes.c_char_p]),
+    "vbnmf_matrix_attach_layout": (ctypes.c_int, [_VP, ctypes.c_char_p]),
     "vbnmf_device_sweep_workgroups": (ctypes.c_int, [_I32, c_int32_p]),
     "vbnmf_device_warmup": (ctypes.c_int, [_I32]),
     "vbnmf_matrix_destroy": (None, [_VP]),

@@ -99,6 +99,30 @@ struct NoInitAlloc : std::allocator<T> {
 };
 template <class T> using BigVec = std::vector<T, NoInitAlloc<T>>;
 
+// The big arrays of a layout (the packed entry stream: 200 MB a side at the headline size) live either in the library's
+// own memory or INSIDE a shared-memory segment mapped by every process of the node (vbnmf_matrix_share_layout /
+// _attach_layout): the builder writes them there as it fills them, the peers map them -- one copy of the layout in host
+// memory per node, no export / import pass.  `keep` holds the mapping for as long as the layout lives.
+template <class T>
+struct ExtVec {
+    using value_type = T;
+    T *p = nullptr;
+    size_t n = 0;
+    BigVec<T> own;
+    std::shared_ptr<void> keep;
+    ExtVec() = default;
+    ExtVec(const ExtVec &) = delete;
+    ExtVec &operator=(const ExtVec &) = delete;
+    T *data() { return p; }
+    const T *data() const { return p; }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    T &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
+    void resize(size_t k) { keep.reset(); own.resize(k); p = own.data(); n = k; }
+    void adopt(T *q, size_t k, std::shared_ptr<void> holder) { BigVec<T>().swap(own); p = q; n = k; keep = std::move(holder); }
+};
+
 struct Layout {
     int side = 0;                   // 0: lanes own genes, minors = cells; 1: lanes own cells, minors = genes
     bool wide = false;
@@ -118,9 +142,16 @@ struct Layout {
     std::vector<uint32_t> inv_task;      // n_tasks     : ... as slice*64+lane ids, in (block, position) order
     std::vector<int32_t> cell_perm;      // cells of the column range in layout order: position -> original local column
                                          // (minors on side 0, majors on side 1; empty = identity).  order.cpp
-    BigVec<uint32_t> packed;             // n_slots (wide == false)
-    BigVec<uint32_t> wide_idx;           // n_slots (wide == true)
-    BigVec<double> wide_val;             // n_slots (wide == true)
+    ExtVec<uint32_t> packed;             // n_slots (wide == false)
+    ExtVec<uint32_t> wide_idx;           // n_slots (wide == true)
+    ExtVec<double> wide_val;             // n_slots (wide == true)
+};
+
+// Where build_layout puts the big arrays: called once the small arrays are final and n_slots is known (null: the
+// library's own memory).  place() must make L.packed (or L.wide_idx / L.wide_val) n_slots long.
+struct LayoutSink {
+    virtual ~LayoutSink() = default;
+    virtual int place(Layout &L) = 0;
 };
 
 struct LayoutParams {
@@ -172,7 +203,8 @@ LayoutParams default_layout_params(int64_t n_major, int64_t n_minor, int R, int 
 
 // Build the layout of `side` for columns [cb, ce) of X, the cells renumbered by `perm` (position -> local column; null or
 // empty: as stored).  The whole matrix (cb = 0, ce = m) must be given X.cell_order(): the cached row-major copy is in it.
-int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const LayoutParams &lp, const std::vector<int32_t> *perm, Layout &out);
+int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const LayoutParams &lp, const std::vector<int32_t> *perm, Layout &out,
+                 LayoutSink *sink = nullptr);
 // order.cpp: the renumbering for columns [cb, ce) (empty: identity / switched off: VBNMF_CELL_ORDER=0; =1 forces it on
 // for every size; default: sparse matrices with at least 8192 cells in the range).
 std::vector<int32_t> compute_cell_order(const Matrix &X, int64_t cb, int64_t ce);
@@ -229,7 +261,8 @@ struct vbnmf_matrix {
 namespace vbnmf {
 // The layout of `side` for the whole matrix at the default geometry of padded rank R: from the matrix's cache, or
 // built now (and cached).  rc != 0 and a null pointer on failure.
-std::shared_ptr<const Layout> shared_layout(const vbnmf_matrix *X, int side, const LayoutParams &lp, int &rc);
+std::shared_ptr<const Layout> shared_layout(const vbnmf_matrix *X, int side, const LayoutParams &lp, int &rc, LayoutSink *sink = nullptr,
+                                            bool *built = nullptr);
 // Device copies of cached layouts: look one up (null if absent) / remember one (ignored if the layout is not cached).
 std::shared_ptr<void> cached_device_copy(const vbnmf_matrix *X, const Layout *L, int device);
 void store_device_copy(const vbnmf_matrix *X, const Layout *L, int device, std::shared_ptr<void> arrays);

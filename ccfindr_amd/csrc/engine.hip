@@ -167,6 +167,14 @@ int dev_alloc(T **p, size_t count)
     return pool_alloc((void **)p, count * sizeof(T));
 }
 
+template <typename T>
+int dev_upload(T **p, const ExtVec<T> &v)
+{
+    if (int rc = dev_alloc(p, v.size())) return rc;
+    if (!v.empty()) HIPCHECK(hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return VBNMF_OK;
+}
+
 template <typename T, typename A>
 int dev_upload(T **p, const std::vector<T, A> &v)
 {

@@ -9,6 +9,11 @@
 #include <algorithm>
 #include <atomic>
 #include <sched.h>
+#include <cerrno>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <chrono>
 #include <system_error>
@@ -366,7 +371,8 @@ LayoutParams default_layout_params(int64_t n_major, int64_t n_minor, int R, int 
     return lp;
 }
 
-int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const LayoutParams &lp, const std::vector<int32_t> *perm_in, Layout &L)
+int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const LayoutParams &lp, const std::vector<int32_t> *perm_in, Layout &L,
+                 LayoutSink *sink)
 {
     const int32_t *perm = (perm_in && !perm_in->empty()) ? perm_in->data() : nullptr;
     if (perm && (int64_t)perm_in->size() != ce - cb) return fail(VBNMF_ERR_BAD_ARG, "cell order has %lld entries for %lld cells", (long long)perm_in->size(), (long long)(ce - cb));
@@ -766,7 +772,8 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
 
     try {
         // not zero-filled (the fill below writes every slot, padding included: first touch by the thread that fills)
-        if (L.wide) { L.wide_idx.resize(L.n_slots); L.wide_val.resize(L.n_slots); }
+        if (sink) { if (int rc = sink->place(L)) return rc; }
+        else if (L.wide) { L.wide_idx.resize(L.n_slots); L.wide_val.resize(L.n_slots); }
         else L.packed.resize(L.n_slots);
     } catch (const std::bad_alloc &) {
         return fail(VBNMF_ERR_OOM, "out of host memory building the tiled layout (%lld slots)", (long long)L.n_slots);
@@ -919,9 +926,10 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
     return VBNMF_OK;
 }
 
-std::shared_ptr<const Layout> shared_layout(const vbnmf_matrix *X, int side, const LayoutParams &lp, int &rc)
+std::shared_ptr<const Layout> shared_layout(const vbnmf_matrix *X, int side, const LayoutParams &lp, int &rc, LayoutSink *sink, bool *built)
 {
     rc = VBNMF_OK;
+    if (built) *built = false;
     const int cap = 2 * std::max(0, env_int("VBNMF_LAYOUT_CACHE", 3));       // entries = pairs x 2 sides
     LayoutCache &C = X->layouts;
     auto same = [&](const LayoutCache::Entry &q) {
@@ -945,12 +953,13 @@ std::shared_ptr<const Layout> shared_layout(const vbnmf_matrix *X, int side, con
         return nullptr;
     }
     auto L = std::make_shared<Layout>();
-    rc = build_layout(X->M, 0, X->M.m, side, lp, &X->M.cell_order(), *L);
+    rc = build_layout(X->M, 0, X->M.m, side, lp, &X->M.cell_order(), *L, sink);
     if (rc) return nullptr;
-    if (cap > 0) {
+    if (built) *built = true;
+    if (cap > 0 || sink) {
         std::lock_guard<std::mutex> g(C.mu);
         C.entries.push_back({side, lp, L});
-        while ((int)C.entries.size() > cap) {
+        while ((int)C.entries.size() > std::max(cap, 2)) {
             const Layout *gone = C.entries.front().layout.get();
             C.entries.erase(C.entries.begin());
             for (size_t i = 0; i < C.copies.size();)          // its device copies live on only in the engines that use them
@@ -1398,7 +1407,12 @@ int vbnmf_matrix_export_layout(const vbnmf_matrix *X, int32_t side, int32_t geom
 
 // Adds the layout in buf[0..bytes) (written by vbnmf_matrix_export_layout, this library version) to X's cache: engines
 // created afterwards in that geometry use it instead of cutting their own.  X: a shell or a full handle of the same matrix.
-int vbnmf_matrix_import_layout(const vbnmf_matrix *X, const void *buf, int64_t bytes)
+}  // extern "C"
+
+namespace {
+// keep == null: every array is copied out of the blob; otherwise the big arrays (entry stream) stay where they are --
+// inside a mapping that `keep` holds for as long as the layout lives.
+int load_blob(const vbnmf_matrix *X, const void *buf, int64_t bytes, std::shared_ptr<void> keep)
 {
     if (!X || !buf) return fail(VBNMF_ERR_BAD_ARG, "NULL argument");
     if (bytes < kBlobHeaderWords * 8 + 8) return fail(VBNMF_ERR_BAD_ARG, "layout blob is truncated (%lld bytes)", (long long)bytes);
@@ -1441,8 +1455,18 @@ int vbnmf_matrix_import_layout(const vbnmf_matrix *X, const void *buf, int64_t b
             }
             o += nb; q++;
         };
+        auto take_big = [&](auto &v) {                       // copied, or adopted in place when the blob is a kept mapping
+            using T = typename std::remove_reference<decltype(v)>::type::value_type;
+            if (!keep) { take(v); return; }
+            o = align64(o);
+            const int64_t nb = h[32 + q];
+            if (nb % (int64_t)sizeof(T)) rc = fail(VBNMF_ERR_BAD_ARG, "layout blob: array %d has a ragged size", q);
+            else v.adopt(reinterpret_cast<T *>(const_cast<char *>(static_cast<const char *>(buf) + o)), (size_t)(nb / (int64_t)sizeof(T)), keep);
+            o += nb; q++;
+        };
         take(L->task_major); take(L->slice_width); take(L->slice_off); take(L->slice_block); take(L->slice_fast); take(L->block_start);
-        take(L->seg_block); take(L->wg_seg0); take(L->seg_ptr); take(L->inv_ptr); take(L->inv_task); take(L->packed); take(L->wide_idx); take(L->wide_val);
+        take(L->seg_block); take(L->wg_seg0); take(L->seg_ptr); take(L->inv_ptr); take(L->inv_task);
+        take_big(L->packed); take_big(L->wide_idx); take_big(L->wide_val);
         take(L->cell_perm);
         if (rc) return rc;
         // the renumbering of the cells: a permutation, and the SAME one for every layout of this matrix (the engine's
@@ -1474,6 +1498,142 @@ int vbnmf_matrix_import_layout(const vbnmf_matrix *X, const void *buf, int64_t b
         return fail(VBNMF_ERR_OOM, "out of host memory importing the layout");
     }
     return VBNMF_OK;
+}
+
+struct ShmMap {
+    void *base = nullptr;
+    size_t bytes = 0;
+    ~ShmMap() { if (base) munmap(base, bytes); }
+};
+
+// The sink of vbnmf_matrix_share_layout: at the point where build_layout knows every size, create `path`.part with the
+// whole blob's size and hand the layout its big arrays INSIDE the mapping.
+struct ShmSink : LayoutSink {
+    std::string path;
+    std::shared_ptr<ShmMap> map;
+    int64_t total = 0;
+    int64_t offs[kBlobArrays] = {};
+    int place(Layout &L) override
+    {
+        // sizes of every array in blob order (the big ones from n_slots: they are not allocated yet)
+        BlobArray a[kBlobArrays];
+        blob_arrays(L, a);
+        const int iP = 11, iWI = 12, iWV = 13;               // packed, wide_idx, wide_val in blob order
+        a[iP].bytes = L.wide ? 0 : L.n_slots * (int64_t)sizeof(uint32_t);
+        a[iWI].bytes = L.wide ? L.n_slots * (int64_t)sizeof(uint32_t) : 0;
+        a[iWV].bytes = L.wide ? L.n_slots * (int64_t)sizeof(double) : 0;
+        int64_t off = kBlobHeaderWords * 8;
+        for (int q = 0; q < kBlobArrays; q++) { off = align64(off); offs[q] = off; off += a[q].bytes; }
+        total = align64(off) + 8;
+        const std::string part = path + ".part";
+        const int fd = open(part.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0) return fail(VBNMF_ERR_BAD_ARG, "cannot create %s: %s", part.c_str(), strerror(errno));
+        if (ftruncate(fd, (off_t)total) != 0) { close(fd); unlink(part.c_str()); return fail(VBNMF_ERR_OOM, "cannot size %s to %lld bytes: %s", part.c_str(), (long long)total, strerror(errno)); }
+        void *base = mmap(nullptr, (size_t)total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (base == MAP_FAILED) { unlink(part.c_str()); return fail(VBNMF_ERR_OOM, "cannot map %s: %s", part.c_str(), strerror(errno)); }
+        map = std::make_shared<ShmMap>();
+        map->base = base; map->bytes = (size_t)total;
+        char *b = static_cast<char *>(base);
+        if (L.wide) {
+            L.wide_idx.adopt(reinterpret_cast<uint32_t *>(b + offs[iWI]), (size_t)L.n_slots, map);
+            L.wide_val.adopt(reinterpret_cast<double *>(b + offs[iWV]), (size_t)L.n_slots, map);
+        } else {
+            L.packed.adopt(reinterpret_cast<uint32_t *>(b + offs[iP]), (size_t)L.n_slots, map);
+        }
+        return VBNMF_OK;
+    }
+};
+
+void write_blob_header(int64_t *h, const Layout &L, const LayoutParams &lp, const vbnmf_matrix *X, int64_t total, const BlobArray (&a)[kBlobArrays])
+{
+    std::memset(h, 0, kBlobHeaderWords * 8);
+    h[0] = kBlobMagic; h[1] = kBlobVersion; h[2] = total;
+    h[3] = L.side; h[4] = L.wide ? 1 : 0; h[5] = L.n_major; h[6] = L.n_minor; h[7] = L.block_width; h[8] = L.n_blocks;
+    h[9] = L.max_len; h[10] = L.n_wg; h[11] = L.row_slots; h[12] = L.n_tasks; h[13] = L.n_slices; h[14] = L.n_slots;
+    h[15] = L.n_segs; h[16] = L.nnz;
+    h[17] = lp.block_width; h[18] = lp.block_cap; h[19] = lp.max_len; h[20] = lp.n_wg; h[21] = lp.row_slots;
+    h[22] = X->M.n; h[23] = X->M.m; h[24] = X->M.nnz;
+    for (int q = 0; q < kBlobArrays; q++) h[32 + q] = a[q].bytes;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vbnmf_matrix_import_layout(const vbnmf_matrix *X, const void *buf, int64_t bytes)
+{
+    return load_blob(X, buf, bytes, nullptr);
+}
+
+// The same layout, but living ONCE in the node's shared memory.  share: cuts the layout with its big arrays written
+// straight into a new file `path` (a tmpfs path, e.g. under /dev/shm; built as path + ".part" and renamed when complete,
+// so a peer that sees `path` sees all of it) and keeps that mapping as the layout's storage; a layout that is already
+// cached in ordinary memory is copied into the file instead.  attach: maps `path` read-only and adopts the big arrays in
+// place (the small index arrays are copied).  The file may be unlinked as soon as every process has attached.
+int vbnmf_matrix_share_layout(const vbnmf_matrix *X, int32_t side, int32_t geometry_rank, int32_t n_wg, const char *path)
+{
+    if (!X || !path) return fail(VBNMF_ERR_BAD_ARG, "NULL argument");
+    if (side != 0 && side != 1) return fail(VBNMF_ERR_BAD_ARG, "side must be 0 or 1");
+    if (geometry_rank < 1 || geometry_rank > VBNMF_MAX_RANK || n_wg < 1) return fail(VBNMF_ERR_BAD_ARG, "bad geometry");
+    try {
+        const LayoutParams lp = whole_matrix_params(X, side, geometry_rank, n_wg);
+        ShmSink sink;
+        sink.path = path;
+        int rc = VBNMF_OK;
+        bool built = false;
+        std::shared_ptr<const Layout> L = shared_layout(X, side, lp, rc, &sink, &built);
+        if (rc) { if (sink.map) unlink((sink.path + ".part").c_str()); return rc; }
+        BlobArray a[kBlobArrays];
+        blob_arrays(*L, a);
+        if (!built || !sink.map) {
+            // already cached in ordinary memory: write a copy (the copying export into a fresh file)
+            int64_t total = kBlobHeaderWords * 8;
+            for (int q = 0; q < kBlobArrays; q++) total = align64(total) + a[q].bytes;
+            total = align64(total) + 8;
+            const std::string part = std::string(path) + ".part";
+            const int fd = open(part.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+            if (fd < 0) return fail(VBNMF_ERR_BAD_ARG, "cannot create %s: %s", part.c_str(), strerror(errno));
+            if (ftruncate(fd, (off_t)total) != 0) { close(fd); unlink(part.c_str()); return fail(VBNMF_ERR_OOM, "cannot size %s: %s", part.c_str(), strerror(errno)); }
+            void *base = mmap(nullptr, (size_t)total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+            close(fd);
+            if (base == MAP_FAILED) { unlink(part.c_str()); return fail(VBNMF_ERR_OOM, "cannot map %s: %s", part.c_str(), strerror(errno)); }
+            int64_t nb = 0;
+            rc = vbnmf_matrix_export_layout(X, side, geometry_rank, n_wg, base, total, &nb);
+            munmap(base, (size_t)total);
+            if (rc) { unlink(part.c_str()); return rc; }
+            if (rename(part.c_str(), path) != 0) { unlink(part.c_str()); return fail(VBNMF_ERR_BAD_ARG, "cannot rename %s: %s", part.c_str(), strerror(errno)); }
+            return VBNMF_OK;
+        }
+        // header, the small arrays and the closing word around the big arrays that build_layout already wrote in place
+        char *b = static_cast<char *>(sink.map->base);
+        write_blob_header(reinterpret_cast<int64_t *>(b), *L, lp, X, sink.total, a);
+        for (int q = 0; q < kBlobArrays; q++) {
+            if (a[q].src == b + sink.offs[q]) continue;                      // a big array: in place already
+            if (a[q].bytes) std::memcpy(b + sink.offs[q], a[q].src, (size_t)a[q].bytes);
+        }
+        std::memcpy(b + sink.total - 8, &kBlobMagic, 8);
+        const std::string part = sink.path + ".part";
+        if (rename(part.c_str(), path) != 0) { unlink(part.c_str()); return fail(VBNMF_ERR_BAD_ARG, "cannot rename %s: %s", part.c_str(), strerror(errno)); }
+    } catch (const std::bad_alloc &) {
+        return fail(VBNMF_ERR_OOM, "out of host memory building the layout");
+    }
+    return VBNMF_OK;
+}
+
+int vbnmf_matrix_attach_layout(const vbnmf_matrix *X, const char *path)
+{
+    if (!X || !path) return fail(VBNMF_ERR_BAD_ARG, "NULL argument");
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return fail(VBNMF_ERR_BAD_ARG, "cannot open %s: %s", path, strerror(errno));
+    struct stat st;
+    if (fstat(fd, &st) != 0 || st.st_size < kBlobHeaderWords * 8 + 8) { close(fd); return fail(VBNMF_ERR_BAD_ARG, "%s is not a layout blob", path); }
+    void *base = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_SHARED, fd, 0);
+    close(fd);
+    if (base == MAP_FAILED) return fail(VBNMF_ERR_OOM, "cannot map %s: %s", path, strerror(errno));
+    auto map = std::make_shared<ShmMap>();
+    map->base = base; map->bytes = (size_t)st.st_size;
+    return load_blob(X, base, (int64_t)st.st_size, map);
 }
 
 }  // extern "C"

@@ -173,6 +173,15 @@ class CountMatrix:
             view = (ctypes.c_char * len(buf)).from_buffer_copy(buf)
         N.check(self._lib.vbnmf_matrix_import_layout(self._h, ctypes.cast(view, ctypes.c_void_p), nbytes))
 
+    def share_layout(self, side, geometry_rank, n_wg, path):
+        """Cuts that layout with its entry stream written straight into the new file ``path`` (a memory file system, e.g.
+        /dev/shm; complete when the name appears) and keeps the mapping as the layout's storage: one copy per node."""
+        N.check(self._lib.vbnmf_matrix_share_layout(self._h, int(side), int(geometry_rank), int(n_wg), os.fsencode(path)))
+
+    def attach_layout(self, path):
+        """Maps a layout file written by ``share_layout`` in another process of the node and uses it in place."""
+        N.check(self._lib.vbnmf_matrix_attach_layout(self._h, os.fsencode(path)))
+
     def plan_ranks(self, ranks=(), max_classes=1):
         """Rank classes for a sweep over several ranks (vbnmf_matrix_plan_ranks): engines created afterwards share the
         tiled layouts of the smallest class at or above their rank instead of cutting a pair per LDS row size.  An empty

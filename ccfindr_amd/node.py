@@ -45,6 +45,25 @@ def fresh_name(tag):
     return f"vbnmf_{tag}_{os.getpid()}_{uuid.uuid4().hex[:12]}"
 
 
+def wait_for(name, timeout_s, failed_name=None):
+    """Block until the file ``name`` exists in the shared directory (its owner renames it into place when complete);
+    raises after ``timeout_s`` or when the owner left a failure note under ``failed_name``."""
+    import time
+    path = os.path.join(shm_dir(), name)
+    t0 = time.perf_counter()
+    while not os.path.exists(path):
+        if failed_name is not None and os.path.exists(os.path.join(shm_dir(), failed_name)):
+            try:
+                msg = open(os.path.join(shm_dir(), failed_name)).read()
+            except OSError:
+                msg = "?"
+            raise RuntimeError(f"the process that cuts the layouts failed: {msg}")
+        if time.perf_counter() - t0 > timeout_s:
+            raise TimeoutError(f"shared file {name} did not appear within {timeout_s:.0f} s")
+        time.sleep(0.0005)
+    return path
+
+
 class Segment:
     """One shared mapping.  ``Segment.create(name, nbytes)`` (owner) / ``Segment.open(name)`` (peer)."""
 

@@ -169,7 +169,7 @@ def vb_factorize_sharded(mat, ranks=2, nrun=1, verbose=0, initializer="random", 
     # still cutting the gene side, and the builder writes one side out (a second host thread) while it cuts the next.
     detail = {} if timings is not None else None
     tick = time.perf_counter
-    cleanup = []                                         # segments this process created (unlinked behind the next barrier)
+    cleanup = []                                         # files this process created (unlinked behind the next barrier)
     if native:
         import threading
         geoms = sorted({geometry_rank_for(r, bundle["classes"]) or int(r) for r in bundle["ranks"]})
@@ -180,44 +180,40 @@ def vb_factorize_sharded(mat, ranks=2, nrun=1, verbose=0, initializer="random", 
         seg_name = lambda b, pc: f"vbnmf_{peers[b]['token']}_g{pc[0]}_s{pc[1]}"
         failed_name = lambda b: f"vbnmf_{peers[b]['token']}_failed"
         wait_s = float(os.environ.get("VBNMF_WAIT_TIMEOUT_S", "300") or 300)
+        seg_path = lambda b, pc: os.path.join(shm.shm_dir(), seg_name(b, pc))
         if sharing and any(b == me for b in builder_of.values()):
-            writers, errors = [], []
+            loaders, errors = [], []
 
-            def write_out(pc):
+            def load(pc):                                # this process's own device copy, beside the cut of the next piece
                 try:
                     t0 = tick()
-                    nb = X.layout_blob_size(pc[1], pc[0], n_wg)                  # (cached by now: the size only)
-                    seg = shm.Segment.create(seg_name(me, pc) + ".part", nb)
-                    cleanup.append(seg)
-                    X.export_layout(pc[1], pc[0], n_wg, seg.map)
-                    seg.publish(seg_name(me, pc))
-                    t1 = tick()
-                    X.preload_layout(pc[1], pc[0], n_wg, device)                 # this process's own device copy, ahead of its first engine
+                    X.preload_layout(pc[1], pc[0], n_wg, device)
                     if detail is not None:
-                        detail[f"export_side{pc[1]}_s"] = t1 - t0
-                        detail[f"preload_side{pc[1]}_s"] = tick() - t1
-                except BaseException as exc:                                     # noqa: BLE001 -- reported through the marker
+                        detail[f"preload_side{pc[1]}_s"] = tick() - t0
+                except BaseException as exc:             # noqa: BLE001
                     errors.append(exc)
 
             try:
-                X.prepare_async()                                                # cell order, then the row-major copy, beside the cut of the cell side
+                X.prepare_async()                        # cell order, then the row-major copy, beside the cut of the cell side
                 for pc in pieces:
                     if builder_of[pc] != me:
                         continue
                     t0 = tick()
-                    X.layout_blob_size(pc[1], pc[0], n_wg)                       # cuts (and caches) the layout
+                    X.share_layout(pc[1], pc[0], n_wg, seg_path(me, pc))         # cut INTO the shared file; the name appears when complete
+                    cleanup.append(seg_path(me, pc))
                     if detail is not None:
                         detail[f"cut_side{pc[1]}_s"] = tick() - t0
-                    th = threading.Thread(target=write_out, args=(pc,))
+                    th = threading.Thread(target=load, args=(pc,))
                     th.start()
-                    writers.append(th)
-                for th in writers:
+                    loaders.append(th)
+                for th in loaders:
                     th.join()
                 if errors:
                     raise errors[0]
             except BaseException as exc:
                 with open(os.path.join(shm.shm_dir(), failed_name(me)), "w") as fh:   # the peers stop polling and raise
                     fh.write(f"{type(exc).__name__}: {exc}")
+                cleanup.append(os.path.join(shm.shm_dir(), failed_name(me)))
                 raise
         if sharing:
             t0 = tick()
@@ -228,18 +224,17 @@ def vb_factorize_sharded(mat, ranks=2, nrun=1, verbose=0, initializer="random", 
                 if peers[b]["n_wg"] != n_wg:
                     raise RuntimeError(f"process {b} cuts layouts for {peers[b]['n_wg']} workgroups, this device wants {n_wg}")
                 t1 = tick()
-                seg = shm.Segment.wait_open(seg_name(b, pc), wait_s, failed_name(b))
+                shm.wait_for(seg_name(b, pc), wait_s, failed_name(b))
                 t2 = tick()
-                X.import_layout(seg.map, seg.size)
-                seg.close()
+                X.attach_layout(seg_path(b, pc))                 # mapped, not copied
                 t3 = tick()
                 X.preload_layout(pc[1], pc[0], n_wg, device)     # upload it now, beside the wait for the next piece
                 if detail is not None:
                     detail[f"wait_side{pc[1]}_s"] = t2 - t1
-                    detail[f"import_side{pc[1]}_s"] = t3 - t2
+                    detail[f"attach_side{pc[1]}_s"] = t3 - t2
                     detail[f"preload_side{pc[1]}_s"] = tick() - t3
             if detail is not None:
-                detail["wait_and_import_s"] = tick() - t0
+                detail["wait_and_attach_s"] = tick() - t0
     if warm is not None:
         warm.join()
     t_layout = time.perf_counter()
@@ -257,8 +252,11 @@ def vb_factorize_sharded(mat, ranks=2, nrun=1, verbose=0, initializer="random", 
             rseg = shm.Segment.open(box[leader])
         dist.barrier(group=group)                        # every process of the node has imported the layouts and mapped the results
         rseg.unlink()                                    # mapped everywhere: the name can go, the memory lives with the mappings
-        for seg in cleanup:
-            seg.close()
+        for path in cleanup:                             # every peer holds its mapping: the names can go
+            try:
+                os.unlink(path)
+            except FileNotFoundError:
+                pass
         bundle["state_out"] = lambda irun, r: _unit_views(rseg, offsets[tasks.index((irun, int(r)))], n, m, int(r))
 
     # A unit that raises (hyper-parameter Newton failure, a VBNMFError, rank > min(nrow, ncol) ...) must not keep this

@@ -140,6 +140,15 @@ int vbnmf_matrix_preload_layout(const vbnmf_matrix *X, int32_t side, int32_t geo
 int vbnmf_matrix_export_layout(const vbnmf_matrix *X, int32_t side, int32_t geometry_rank, int32_t n_wg,
                                void *buf, int64_t capacity, int64_t *bytes);
 int vbnmf_matrix_import_layout(const vbnmf_matrix *X, const void *buf, int64_t bytes);
+/* The same without the two copies: ONE copy of a layout's big arrays (the packed entry stream, 200 MB a side at the
+ * headline size) per node, in a file on a memory file system that every process maps.
+ *   share  : cuts the layout with the entry stream written straight INTO the new file `path` (built as path + ".part" and
+ *            renamed when complete: a peer that sees `path` sees all of it); the mapping stays the layout's storage in
+ *            this process.  (A layout already cached in ordinary memory is copied into the file instead.)
+ *   attach : maps `path` read-only and adopts the entry stream in place; the small index arrays are copied.
+ * The file can be unlinked once every process has attached; the memory lives as long as a mapping does. */
+int vbnmf_matrix_share_layout(const vbnmf_matrix *X, int32_t side, int32_t geometry_rank, int32_t n_wg, const char *path);
+int vbnmf_matrix_attach_layout(const vbnmf_matrix *X, const char *path);
 /* Persistent workgroups of the sweep kernels on `device` (one per CU; VBNMF_NWG overrides): the n_wg of the layouts
  * that whole-matrix engines on that device use. */
 int vbnmf_device_sweep_workgroups(int32_t device, int32_t *n_wg);

@@ -158,3 +158,35 @@ def test_two_seeds_give_independent_hashes():
     assert lib_hash(w, A) == lib_hash(v, A)                              # the constructed collision is real ...
     assert lib_hash(w, B) != lib_hash(v, B)                              # ... and the second seed tells the buffers apart
     assert lib_hash(w, A) != lib_hash(w, B)
+
+
+@pytest.mark.parametrize("wide", [False, True])
+def test_share_and_attach_a_layout_without_copies(wide, tmp_path):
+    """vbnmf_matrix_share_layout cuts a layout with its entry stream INSIDE a file of the memory file system (complete when
+    the name appears); vbnmf_matrix_attach_layout maps it in another handle and uses it in place.  The attached layout must
+    be the layout a plain cut gives (same blob through the copying export), and survive the file's unlinking."""
+    import ccfindr_amd as C
+    from ccfindr_amd import node
+    X = _matrix(seed=9, wide=wide)
+    plain = C.CountMatrix(X)                                      # reference: cut in ordinary memory
+    sharer = C.CountMatrix(X)
+    shell = C.CountMatrix.shell(sharer.meta())
+    for side in (1, 0):
+        nb = plain.layout_blob_size(side, 8, 256)
+        want = bytearray(nb)
+        plain.export_layout(side, 8, 256, want)
+        path = os.path.join(node.shm_dir(), node.fresh_name(f"share{side}"))
+        sharer.share_layout(side, 8, 256, path)
+        assert os.path.exists(path) and not os.path.exists(path + ".part") and os.path.getsize(path) == nb
+        assert open(path, "rb").read() == bytes(want)             # the file IS the blob, byte for byte
+        shell.attach_layout(path)
+        os.unlink(path)                                           # the mappings keep the memory
+        for handle in (sharer, shell):                            # both now serve the layout from the mapping
+            back = bytearray(nb)
+            assert handle.export_layout(side, 8, 256, back) == nb and back == want
+        # a second share of the SAME geometry (cached by now) falls back to writing a copy
+        path2 = os.path.join(node.shm_dir(), node.fresh_name(f"again{side}"))
+        sharer.share_layout(side, 8, 256, path2)
+        assert open(path2, "rb").read() == bytes(want)
+        os.unlink(path2)
+    plain.close(); sharer.close(); shell.close()
