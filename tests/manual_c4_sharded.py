@@ -24,7 +24,7 @@ sys.path.insert(0, ROOT)
 RANKS = list(range(2, 21))
 
 
-def worker(rank, world, port, path, q):
+def worker(rank, world, port, path, q, concurrent=1):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     import scipy.sparse as sp
@@ -57,7 +57,7 @@ def worker(rank, world, port, path, q):
         tm = {}
         dist.barrier()
         t0 = time.perf_counter()
-        res = parallel.vb_factorize_sharded(M, ranks=RANKS, nrun=1, Itmax=2000, Tol=1e-5, seed=7, device=0, timings=tm)
+        res = parallel.vb_factorize_sharded(M, ranks=RANKS, nrun=1, Itmax=2000, Tol=1e-5, seed=7, device=0, timings=tm, concurrent=concurrent)
         t_all = time.perf_counter() - t0
         dist.barrier()
         t_wall = time.perf_counter() - t0                     # until the slowest process has its result
@@ -71,12 +71,12 @@ def worker(rank, world, port, path, q):
         dist.destroy_process_group()
 
 
-def run_world(world, path):
+def run_world(world, path, concurrent=1):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 30900 + (os.getpid() % 500) + world
-    procs = [ctx.Process(target=worker, args=(k, world, port, path, q)) for k in range(world)]
+    procs = [ctx.Process(target=worker, args=(k, world, port, path, q, concurrent)) for k in range(world)]
     t0 = time.perf_counter()
     for p in procs:
         p.start()
@@ -86,7 +86,7 @@ def run_world(world, path):
     wall = time.perf_counter() - t0
     assert all(o["nsteps_all_ranks"] == outs[0]["nsteps_all_ranks"] and o["lml"] == outs[0]["lml"] and
                o["result_sha256"] == outs[0]["result_sha256"] for o in outs), "the processes disagree on the result"
-    return {"processes": world, "wall_s_including_process_start_and_import": wall,
+    return {"processes": world, "concurrent_units_per_process": concurrent, "wall_s_including_process_start_and_import": wall,
             "sharded_call_s_max": max(o["sharded_call_s"] for o in outs),
             "overhead_s_max": max(o["overhead_s"] for o in outs), "per_process": outs}
 
@@ -94,6 +94,7 @@ def run_world(world, path):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--procs", default="1,2,4,6")
+    ap.add_argument("--concurrent", type=int, default=1)
     args = ap.parse_args()
     import bench
     name, X, _ = bench.make_workload(False)
@@ -102,7 +103,7 @@ def main():
     np.savez(path, data=X.data, indices=X.indices, indptr=X.indptr, shape=np.asarray(X.shape))
     rows = []
     for world in [int(v) for v in args.procs.split(",")]:
-        row = run_world(world, path)
+        row = run_world(world, path, args.concurrent)
         rows.append(row)
         print(f"P={world}: call {row['sharded_call_s_max']:.2f} s (slowest process), overhead beside stepping {row['overhead_s_max']:.2f} s", flush=True)
         for o in row["per_process"]:
