@@ -491,8 +491,9 @@ int launch_update(vbnmf_engine *e, bool gene_side, double a, double b, double fu
     double *l = gene_side ? e->lw : e->lh, *ll = gene_side ? e->llw : e->llh;
     double *ev = gene_side ? e->ew : e->eh, *d = gene_side ? e->dw : e->dh;
     double *bp = gene_side ? e->bpW : e->bpH;
+    static const int stage_ids = [] { const char *v = getenv("VBNMF_NO_STAGE_IDS"); return (v && v[0] == '1') ? 0 : 1; }();   // A/B switch
     switch (e->R) {
-#define X(RR) case RR: hipLaunchKernelGGL((k_update<RR>), dim3(grid), dim3(kUpdateThreads), 0, e->stream, acc, inv_ptr, inv_task, nmaj, e->r, other, other_bp, other_nb, a, b, lga, fudge, l, ll, ev, d, bp, ctl, side, fold); break;
+#define X(RR) case RR: hipLaunchKernelGGL((k_update<RR>), dim3(grid), dim3(kUpdateThreads), 0, e->stream, acc, inv_ptr, inv_task, nmaj, e->r, other, other_bp, other_nb, a, b, lga, fudge, l, ll, ev, d, bp, ctl, side, fold, stage_ids); break;
         VBNMF_FOR_EACH_R(X)
 #undef X
         default: return fail(VBNMF_ERR_BAD_ARG, "unsupported padded rank %d", e->R);

@@ -536,11 +536,30 @@ __device__ __forceinline__ double task_sum(const double *__restrict__ part, cons
     return s;
 }
 
+// The same with the ids read from an LDS copy of the block's stretch of the inverse index (k_update stages it once per
+// block): the value loads of a major no longer wait for a global round trip that fetches their ids, and the rounds of one
+// sum are independent of each other.  Same summation order: bit-identical results.
+__device__ __forceinline__ double task_sum_lds(const double *__restrict__ part, const uint32_t *ids, int q0, int q1, int R, int k)
+{
+    double s = 0.0;
+    constexpr int NF = VBNMF_GATHER_WIDTH;
+    for (int q = q0; q < q1; q += NF) {
+        double v[NF];
+#pragma unroll
+        for (int u = 0; u < NF; u++) v[u] = part[(size_t)ids[min(q + u, q1 - 1)] * R + k];
+#pragma unroll
+        for (int u = 0; u < NF; u++) s += (q + u < q1) ? v[u] : 0.0;
+    }
+    return s;
+}
+
 // ------------------------------------------------------------------------------------
 // Small fixed-order reductions used by the update / final kernels.
 // ------------------------------------------------------------------------------------
 constexpr int kUpdateBlocks = 256;     // persistent blocks of k_update / k_prime (one per CU)
 constexpr int kUpdateThreads = 1024;
+constexpr int kStageIds = 14336;       // task ids of a block's majors staged in LDS by k_update (56 KB) ...
+constexpr int kStagePtr = 2048;        // ... and their pointer stretch (8 KB); a block with more falls back to global reads
 
 __device__ __forceinline__ double wave_sum(double v)
 {
@@ -630,13 +649,30 @@ __global__ __launch_bounds__(kUpdateThreads) void k_update(
     int64_t nmaj, int r, const double *__restrict__ other, const double *__restrict__ other_bp, int other_nb,
     double a, double b, double lga, double fudge,
     double *__restrict__ l, double *__restrict__ ll, double *__restrict__ e, double *__restrict__ d, double *__restrict__ bp,
-    const LoopCtl *__restrict__ ctl, int side, const ControlFold fold)
+    const LoopCtl *__restrict__ ctl, int side, const ControlFold fold, int stage_ids)
 {
     constexpr int RB = kUpdateThreads / R;       // majors per pass
     __shared__ double s_other[R + 2];
     __shared__ double s_e[kUpdateThreads], s_t[kUpdateThreads], s_l[kUpdateThreads];
+    __shared__ uint32_t s_ids[kStageIds];
+    __shared__ int32_t s_ptr[kStagePtr];
     int stopped = 0;
     const int t = threadIdx.x;
+    // The block's stretch of the inverse index into LDS, first thing: two dependent global round trips (pointers, then
+    // ids) that the prologue's own loads overlap with, instead of two per ROUND of every major's gather below.
+    const int64_t per0 = (nmaj + gridDim.x - 1) / gridDim.x;
+    const int64_t bm0 = (int64_t)blockIdx.x * per0, bm1 = min(nmaj, bm0 + per0);
+    int q_lo = 0;
+    bool staged = false;
+    if (stage_ids && inv_ptr && !fold.control_only && bm0 < bm1 && bm1 - bm0 < kStagePtr) {
+        q_lo = inv_ptr[bm0];
+        const int q_hi = inv_ptr[bm1];
+        staged = q_hi - q_lo <= kStageIds;               // (block-uniform)
+        if (staged) {
+            for (int q = t; q <= (int)(bm1 - bm0); q += kUpdateThreads) s_ptr[q] = inv_ptr[bm0 + q];
+            for (int q = q_lo + t; q < q_hi; q += kUpdateThreads) s_ids[q - q_lo] = inv_task[q];
+        }
+    }
     if (fold.prev) {
         // ---- the folded control step (see ControlFold; the arithmetic is k_control's, statement by statement) ----
         __shared__ double sW[R + 2], s_hy[4];
@@ -736,7 +772,9 @@ __global__ __launch_bounds__(kUpdateThreads) void k_update(
         for (int64_t M = m0 + row; M < m1; M += RB) {
             const size_t o = (size_t)M * R + k;
             if (k < r) {
-                const double s = inv_ptr ? task_sum(acc, inv_task, inv_ptr[M], inv_ptr[M + 1], R, k) : acc[o];
+                const double s = !inv_ptr ? acc[o]
+                                 : staged ? task_sum_lds(acc, s_ids, s_ptr[M - bm0] - q_lo, s_ptr[M - bm0 + 1] - q_lo, R, k)
+                                          : task_sum(acc, inv_task, inv_ptr[M], inv_ptr[M + 1], R, k);
                 const double al = a + l[o] * s;
                 const double ev = al / be;
                 const double dv = al / be / be;
