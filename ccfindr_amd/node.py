@@ -28,6 +28,18 @@ def shm_dir():
     return d
 
 
+def free_bytes():
+    """Bytes still available in the shared directory (a tmpfs that is full answers writes with SIGBUS, so callers ask first)."""
+    forced = os.environ.get("VBNMF_TEST_SHM_FREE")          # tests: pretend the file system has this many bytes left
+    if forced:
+        return int(forced)
+    try:
+        st = os.statvfs(shm_dir())
+        return int(st.f_bavail) * int(st.f_frsize)
+    except OSError:
+        return 0
+
+
 def node_key():
     """What two processes must agree on to share /dev/shm: host name + the kernel's boot id.  ``VBNMF_NODE_KEY`` overrides
     (tests use it to rehearse the several-nodes path on one machine)."""

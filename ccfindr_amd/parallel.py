@@ -118,7 +118,7 @@ def vb_factorize_sharded(mat, ranks=2, nrun=1, verbose=0, initializer="random", 
         X = mat if isinstance(mat, CountMatrix) or not native else CountMatrix(mat)
     # ---- control plane, round 1 (tiny host objects): who holds X, on which node, and what the guards found
     mine = {"node": shm.node_key(), "holds": X is not None, "meta": None, "empty": (0, 0), "n_wg": 0,
-            "token": f"{os.getpid()}_{uuid.uuid4().hex[:10]}"}
+            "token": f"{os.getpid()}_{uuid.uuid4().hex[:10]}", "shm_free": shm.free_bytes()}
     if X is not None and native:
         mine["meta"] = [float(v) for v in X.meta()]
         mine["empty"] = (0, 0) if X.is_shell else tuple(X.empty_counts())            # reference R/bayesian.R:244-247
@@ -145,6 +145,28 @@ def vb_factorize_sharded(mat, ranks=2, nrun=1, verbose=0, initializer="random", 
             raise ValueError("Input matrix contains empty rows")
         if peers[p]["empty"][1] > 0:
             raise ValueError("Input matrix contains empty columns")
+    # Room in each node's memory file system for what is about to be put there (a container may give /dev/shm 64 MB: writing
+    # past a full tmpfs is a SIGBUS, not an error code).  Estimate: per geometry two entry streams of 4 B (12 B for
+    # non-integer X) per stored entry + 15 %, and the units' four factor matrices.  A node with too little room is taken
+    # apart: each of its processes then works alone (its own layouts, results by tensor broadcast), which needs X on all of
+    # them.  Every process evaluates every node from the same gathered numbers, so all take the same decisions.
+    any_meta = next(peers[p]["meta"] for p in range(world) if peers[p]["holds"])
+    geoms_n = max(1, len(set(int(r) for r in np.atleast_1d(ranks))) if not geometry_classes else int(geometry_classes))
+    entry_b = 4 if (len(any_meta) > 3 and any_meta[3]) else 12
+    need = sum(16.0 * (any_meta[0] * r + r * any_meta[1]) for r in np.atleast_1d(ranks)) * nrun
+    if native:
+        need += geoms_n * 2 * (float(any_meta[2]) * entry_b * 1.15 + 64e6)
+    for key in sorted({q["node"] for q in peers}):
+        members = [p for p in range(world) if peers[p]["node"] == key]
+        if len(members) > 1 and min(peers[p]["shm_free"] for p in members) < 1.25 * need:
+            lacking = [p for p in members if not peers[p]["holds"]]
+            if lacking:
+                raise RuntimeError(f"processes {lacking} hold no copy of X and the memory file system of their node has room for "
+                                   f"{min(peers[p]['shm_free'] for p in members) / 1e9:.2f} GB of the {1.25 * need / 1e9:.2f} GB its "
+                                   "processes would share; give every process the matrix or point VBNMF_SHM_DIR at a larger one")
+            for p in members:
+                peers[p]["node"] = f"{key}#alone{p}"
+    mine = peers[me]
     my_node = [p for p in range(world) if peers[p]["node"] == mine["node"]]
     node_holders = [p for p in my_node if peers[p]["holds"]]
     if not node_holders:

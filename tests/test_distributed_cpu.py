@@ -128,7 +128,10 @@ def test_sharded_sweep_unit_failure_reaches_every_rank():
 def _two_node_worker(rank, world, port, q):
     sys.path.insert(0, ROOT); sys.path.insert(0, HERE)
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
-    os.environ["VBNMF_NODE_KEY"] = f"pretend-node-{rank}"          # no shared /dev/shm between the two processes
+    if os.environ.get("TEST_TINY_SHM"):
+        os.environ["VBNMF_TEST_SHM_FREE"] = "4096"                  # one node, but its /dev/shm is (said to be) full
+    else:
+        os.environ["VBNMF_NODE_KEY"] = f"pretend-node-{rank}"      # no shared /dev/shm between the two processes
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from fake_engine import NumpyPhaseEngine
@@ -143,9 +146,14 @@ def _two_node_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_sharded_sweep_across_two_pretend_nodes_uses_tensor_broadcasts():
-    """Processes that share no /dev/shm (forced through VBNMF_NODE_KEY): a unit's factor matrices reach the other node by
-    tensor broadcast from its owner; the result is still the serial one, bit for bit, on every process."""
+@pytest.mark.parametrize("tiny_shm", [False, True])
+def test_sharded_sweep_across_two_pretend_nodes_uses_tensor_broadcasts(tiny_shm, monkeypatch):
+    """Processes that share no /dev/shm (forced through VBNMF_NODE_KEY) -- or whose /dev/shm has no room for the layouts and
+    results (a container's 64 MB default; writing past a full tmpfs would be a SIGBUS), in which case the node is taken apart
+    and every process works alone: a unit's factor matrices reach the others by tensor broadcast from its owner; the
+    result is still the serial one, bit for bit, on every process."""
+    if tiny_shm:
+        monkeypatch.setenv("TEST_TINY_SHM", "1")
     sys.path.insert(0, HERE)
     from fake_engine import NumpyPhaseEngine
     import ccfindr_amd as C
