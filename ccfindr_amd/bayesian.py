@@ -493,6 +493,14 @@ def vb_factorize(mat, ranks=2, nrun=1, verbose=2, progress_bar=True, initializer
     try:
         if bundle["concurrent"] > 1:
             from concurrent.futures import ThreadPoolExecutor
+            if engine_factory is None and not getattr(bundle["mat"], "is_shell", False):
+                # several units in flight: cut (and upload) the sweep's layouts once, here, instead of letting the first
+                # units' threads cut the same pair side by side
+                from .engine import sweep_workgroups
+                n_wg = sweep_workgroups(device)
+                for g in sorted({geometry_rank_for(r, bundle["classes"]) or int(r) for r in bundle["ranks"]}):
+                    for side in (1, 0):
+                        bundle["mat"].preload_layout(side, g, n_wg, device)
             units = [(irun, int(r)) for irun in range(1, nrun + 1) for r in bundle["ranks"]]
             units.sort(key=lambda u: -u[1])                                      # longest first
             with ThreadPoolExecutor(max_workers=bundle["concurrent"]) as pool:

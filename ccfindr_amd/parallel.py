@@ -260,6 +260,11 @@ def vb_factorize_sharded(mat, ranks=2, nrun=1, verbose=0, initializer="random", 
                     detail[f"preload_side{pc[1]}_s"] = tick() - t3
             if detail is not None:
                 detail["wait_and_attach_s"] = tick() - t0
+        if not sharing and int(concurrent) > 1 and not X.is_shell:
+            # nobody to share with, but several units in flight: cut (and upload) the sweep's layouts once, here, instead of
+            # letting the first units' threads cut the same pair side by side
+            for pc in pieces:
+                X.preload_layout(pc[1], pc[0], n_wg, device)
     if warm is not None:
         warm.join()
     t_layout = time.perf_counter()

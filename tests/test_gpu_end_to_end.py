@@ -50,3 +50,35 @@ def test_concurrent_units_give_the_same_result():
         assert np.array_equal(x, y)
     print(f"sequential {ta:.2f} s, concurrent=4 {tb:.2f} s")
     M.close()
+
+
+def test_layouts_uploaded_ahead_of_the_first_engine_change_nothing():
+    """vbnmf_device_warmup / vbnmf_matrix_prepare_async / vbnmf_matrix_preload_layout only move work earlier (the sharded
+    sweep's peers spend their wait for the layouts there): an engine created afterwards is bit-identical to one created cold,
+    and a second preload of the same geometry is a no-op."""
+    import ccfindr_amd as C
+    from ccfindr_amd import synth
+    from ccfindr_amd.engine import device_warmup, sweep_workgroups
+    hy = {"aw": 1.0, "bw": 1.0, "ah": 1.0, "bh": 1.0}
+    X = synth.fill_empty(synth.simulate_data(500, [300, 400], alpha0=0.2, seed=21, depth=np.full(700, 100)), seed=21)
+    n, m = X.shape
+    wh = synth.random_state(n, m, 6, hy, seed=4)
+    outs = []
+    for warm in (False, True):
+        M = C.CountMatrix(X)
+        if warm:
+            device_warmup(0)
+            M.prepare_async()
+            n_wg = sweep_workgroups(0)
+            for side in (1, 0):
+                M.preload_layout(side, 8, n_wg, 0)
+                M.preload_layout(side, 8, n_wg, 0)
+            M.prepare()
+        eng = C.VBEngine(M, 6, geometry_rank=8)
+        eng.set_state(wh["lw"], wh["lh"], wh["eh"])
+        res = eng.run(hy, Itmax=12, Tol=0.0, flags=(True,) * 4, history=True)
+        outs.append((res["history"], eng.get_state()))
+        eng.close(); M.close()
+    assert np.array_equal(outs[0][0], outs[1][0])
+    for k in outs[0][1]:
+        assert np.array_equal(outs[0][1][k], outs[1][1][k]), k
