@@ -72,7 +72,7 @@ def _unit_views(seg, base, n, m, r):
 def vb_factorize_sharded(mat, ranks=2, nrun=1, verbose=0, initializer="random", Itmax=10000,
                          hyper_update=(True, True, True, True), gamma_a=1, gamma_b=1, Tol=1e-5,
                          hyper_update_n0=10, hyper_update_dn=1, fudge=None, unif_stop=True, seed=0,
-                         device=None, group=None, engine_factory=None, geometry_classes=1, timings=None, concurrent=2):
+                         device=None, group=None, engine_factory=None, geometry_classes=1, timings=None, concurrent=4):
     """``vb_factorize`` with the (run, rank) units sharded over the ranks of a process group.
 
     Call it from every process (``torch.distributed`` initialised, one process per GPU).  Every process returns the
@@ -95,7 +95,8 @@ def vb_factorize_sharded(mat, ranks=2, nrun=1, verbose=0, initializer="random", 
     the call: ``layout_s`` (cut / export / wait / import), ``units_s``, ``gather_s``.  ``concurrent`` > 1 keeps that many of
     this process's units in flight on its GPU (one engine, HIP stream and host thread each, as ``vb_factorize``): the
     host side of one unit -- initial state, its upload, the result's download -- then runs beside another unit's stepping
-    (C4 rehearsal, two processes on one GPU: 1.00 -> 0.83 s); results do not depend on it.  Default 2.
+    (C4 rehearsal on one GPU, one process: 1.08 s one at a time, 0.73 s with two, 0.60-0.66 s with four); results do not depend
+    on it.  Default 4.
     """
     import os
     import time

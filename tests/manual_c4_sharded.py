@@ -94,7 +94,7 @@ def run_world(world, path, concurrent=1):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--procs", default="1,2,4,6")
-    ap.add_argument("--concurrent", type=int, default=2)
+    ap.add_argument("--concurrent", type=int, default=4)
     args = ap.parse_args()
     import bench
     name, X, _ = bench.make_workload(False)
