@@ -491,7 +491,10 @@ int launch_update(vbnmf_engine *e, bool gene_side, double a, double b, double fu
     double *l = gene_side ? e->lw : e->lh, *ll = gene_side ? e->llw : e->llh;
     double *ev = gene_side ? e->ew : e->eh, *d = gene_side ? e->dw : e->dh;
     double *bp = gene_side ? e->bpW : e->bpH;
-    static const int stage_ids = [] { const char *v = getenv("VBNMF_NO_STAGE_IDS"); return (v && v[0] == '1') ? 0 : 1; }();   // A/B switch
+    static const int stage_allowed = [] { const char *v = getenv("VBNMF_NO_STAGE_IDS"); return (v && v[0] == '1') ? 0 : 1; }();   // A/B switch
+    // (staging the inverse index in LDS pays from a few hundred task ids per block on: on tiny matrices its two leading
+    // round trips are all there is to the kernel -- 200 x 500 at rank 3: 30.7 -> 31.3 us per step with it)
+    const int stage_ids = stage_allowed && !dense && S.n_tasks >= (int64_t)256 * grid ? 1 : 0;
     switch (e->R) {
 #define X(RR) case RR: hipLaunchKernelGGL((k_update<RR>), dim3(grid), dim3(kUpdateThreads), 0, e->stream, acc, inv_ptr, inv_task, nmaj, e->r, other, other_bp, other_nb, a, b, lga, fudge, l, ll, ev, d, bp, ctl, side, fold, stage_ids); break;
         VBNMF_FOR_EACH_R(X)

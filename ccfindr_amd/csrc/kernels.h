@@ -772,22 +772,37 @@ __global__ __launch_bounds__(kUpdateThreads) void k_update(
         for (int64_t M = m0 + row; M < m1; M += RB) {
             const size_t o = (size_t)M * R + k;
             if (k < r) {
+#ifdef VBNMF_ABL_NOGATHER                                    /* ablation builds only (profiles/ubench/r04/upd_ablate.sh) */
+                const double s = 1.0 + 1e-9 * (double)k;
+#else
                 const double s = !inv_ptr ? acc[o]
                                  : staged ? task_sum_lds(acc, s_ids, s_ptr[M - bm0] - q_lo, s_ptr[M - bm0 + 1] - q_lo, R, k)
                                           : task_sum(acc, inv_task, inv_ptr[M], inv_ptr[M + 1], R, k);
+#endif
                 const double al = a + l[o] * s;
                 const double ev = al / be;
                 const double dv = al / be / be;
                 double psi, lgam;
+#ifdef VBNMF_ABL_NOSPECIAL
+                psi = al * 0.5; lgam = al * 0.25;
+                const double tmp = psi / be;
+                const double ln = (tmp > fudge ? tmp : fudge);
+                const double lg = ln * 0.125;
+#else
                 dev_psi_lgamma(al, &psi, &lgam);
                 if (!(al > 0.0)) { psi = __builtin_nan(""); lgam = __builtin_nan(""); }
                 const double tmp = exp(psi) / be;
                 const double ln = (tmp > fudge ? tmp : fudge);
                 const double lg = log(ln);
+#endif
                 ve += ev;
                 vt += -(a / b) * ev + lga + al * (1.0 - lbe) + lgam;
                 vl += lg;
+#ifdef VBNMF_ABL_NOWRITE
+                if (ln == 123.456) { l[o] = ln; ll[o] = ln * lg; e[o] = ev; d[o] = dv; }
+#else
                 l[o] = ln; ll[o] = ln * lg; e[o] = ev; d[o] = dv;
+#endif
             } else {
                 l[o] = 0.0; ll[o] = 0.0; e[o] = 0.0; d[o] = 0.0;
             }
