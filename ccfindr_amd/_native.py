@@ -114,6 +114,7 @@ SIGNATURES = {
     "vbnmf_engine_layout_info": (ctypes.c_int, [_VP] + [c_int64_p] * 6),
     "vbnmf_engine_debug_times": (ctypes.c_int, [_VP, ctypes.POINTER(ctypes.c_uint64), _I64, c_int32_p, c_int32_p]),
     "vbnmf_stateless_cache_clear": (None, []),
+    "vbnmf_pool_trim": (None, []),
     "vbnmf_update_dense": (ctypes.c_int, [_I64, _I64, _I32, c_double_p, c_double_p, c_double_p, c_double_p]
                            + [_D] * 5 + [c_double_p] * 7),
     "vbnmf_update_csc": (ctypes.c_int, [_I64, _I64, _I32, c_int32_p, c_int32_p, c_double_p,

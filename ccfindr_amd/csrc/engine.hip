@@ -2494,6 +2494,15 @@ int with_csc(int64_t n, int64_t m, int32_t r, const int32_t *p, const int32_t *i
 
 extern "C" {
 
+// Gives every device buffer the pool holds back to the driver (buffers in use by live engines are not touched).
+void vbnmf_pool_trim(void)
+{
+    DevicePool &P = device_pool();
+    std::vector<PoolBuf> drop;
+    { std::lock_guard<std::mutex> g(P.mu); drop.swap(P.free_list); P.held = 0; }
+    for (const PoolBuf &b : drop) (void)hipFree(b.p);
+}
+
 void vbnmf_stateless_cache_clear(void)
 {
     StatelessCache &C = stateless_cache();

@@ -322,6 +322,10 @@ int vbnmf_update_dense(int64_t n, int64_t m, int32_t r, const double *X,
  * and one step instead of ingestion + layouts + engine.  Results do not depend on it.  VBNMF_STATELESS_CACHE=0 disables it;
  * vbnmf_stateless_cache_clear() releases what is held (device and host memory). */
 void vbnmf_stateless_cache_clear(void);
+/* Device buffers of destroyed engines are kept in a per-process pool (at most VBNMF_POOL_MB, default 4096) for the next
+ * engine: a rank sweep creates and destroys one engine per (run, rank) unit and every hipFree synchronises the device.
+ * This returns what the pool holds to the driver. */
+void vbnmf_pool_trim(void);
 /* Same with X as dgCMatrix slots (no densification on the R side). */
 int vbnmf_update_csc(int64_t n, int64_t m, int32_t r, const int32_t *p, const int32_t *i,
                      const double *x,
