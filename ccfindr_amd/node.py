@@ -97,30 +97,6 @@ class Segment:
         os.close(fd)
         return cls(name, mapping, max(int(nbytes), 1), True)
 
-    def publish(self, name):
-        """Rename the (fully written) segment to ``name``: peers that poll for that name see it complete or not at all."""
-        os.rename(os.path.join(shm_dir(), self.name), os.path.join(shm_dir(), name))
-        self.name = name
-
-    @classmethod
-    def wait_open(cls, name, timeout_s, failed_name=None):
-        """Open ``name`` as soon as its owner has published it; raises after ``timeout_s`` or when the owner left a failure
-        note under ``failed_name``."""
-        import time
-        path = os.path.join(shm_dir(), name)
-        t0 = time.perf_counter()
-        while not os.path.exists(path):
-            if failed_name is not None and os.path.exists(os.path.join(shm_dir(), failed_name)):
-                try:
-                    msg = open(os.path.join(shm_dir(), failed_name)).read()
-                except OSError:
-                    msg = "?"
-                raise RuntimeError(f"the process that cuts the layouts failed: {msg}")
-            if time.perf_counter() - t0 > timeout_s:
-                raise TimeoutError(f"shared segment {name} did not appear within {timeout_s:.0f} s")
-            time.sleep(0.0005)
-        return cls.open(name)
-
     @classmethod
     def open(cls, name):
         path = os.path.join(shm_dir(), name)
