@@ -32,7 +32,9 @@ a short K measures the chip at its loaded clocks, not on its way up from idle.
   python bench.py [--gpus N] [--steps K] [--warmup W] [--mode restarts|cells] [--small]
 
 Beside the headline, at every N: `rank_sweep` = BASELINE config C4 (ranks 2..20 on the same matrix through
-vb_factorize_sharded, reference defaults: wall seconds, per-rank iterations, stepping / setup split per process); at N > 1
+vb_factorize_sharded, reference defaults: wall seconds of the call as the library runs it -- four units in flight per
+process --, per-rank iterations, and from a second call with ONE unit at a time the stepping / setup split per process;
+that second call finds the sweep's layouts already cut); at N > 1
 also `cells_partitioned` = config C5 (one factorisation, cells partitioned N-way, the library's all-reduce inside the
 device-driven loop) with its per-GPU roofline and `allreduce_ms` (events around the collective).
 
@@ -243,29 +245,41 @@ def rank_sweep_sample(M, world, rank, local_rank, barrier, small=False):
     import torch.distributed as dist
     from ccfindr_amd import parallel
     ranks = list(range(2, 7)) if small else list(range(2, 21))
-    tm = {}
-    barrier()
-    t0 = time.perf_counter()
-    res = parallel.vb_factorize_sharded(M, ranks=ranks, nrun=1, Itmax=2000, Tol=1e-5, seed=7, device=local_rank, timings=tm)
-    t_call = time.perf_counter() - t0
-    barrier()
-    t_wall = time.perf_counter() - t0
-    units = tm.get("unit_detail") or []
-    mine = {"process": rank, "call_s": t_call, "layouts_s": tm["layout_s"], "units_s": tm["units_s"], "exchange_s": tm["gather_s"],
-            "stepping_s": sum(u["loop_s"] for u in units), "ranks": [u["rank"] for u in units],
-            "layout_detail": tm.get("layout_detail")}
-    mine["setup_s"] = t_call - mine["stepping_s"]
-    rows = [mine]
-    if world > 1:
-        rows = [None] * world
-        dist.all_gather_object(rows, mine)                       # (small records; outside the timed call)
+
+    def one_call(concurrent):
+        tm = {}
+        barrier()
+        t0 = time.perf_counter()
+        res = parallel.vb_factorize_sharded(M, ranks=ranks, nrun=1, Itmax=2000, Tol=1e-5, seed=7, device=local_rank, timings=tm,
+                                            concurrent=concurrent)
+        t_call = time.perf_counter() - t0
+        barrier()
+        t_wall = time.perf_counter() - t0
+        units = tm.get("unit_detail") or []
+        mine = {"process": rank, "call_s": t_call, "layouts_s": tm["layout_s"], "units_s": tm["units_s"], "exchange_s": tm["gather_s"],
+                "stepping_s": sum(u["loop_s"] for u in units), "ranks": [u["rank"] for u in units]}
+        mine["setup_s"] = t_call - mine["stepping_s"]
+        rows = [mine]
+        if world > 1:
+            rows = [None] * world
+            dist.all_gather_object(rows, mine)                   # (small records; outside the timed call)
+        return res, t_wall, rows
+
+    # the call as the library runs it (several units in flight per process: their host sides overlap other units' stepping,
+    # so stepping and set-up cannot be told apart) ...
+    res, wall, rows = one_call(4)
+    # ... and once more with ONE unit at a time, for the split into device stepping and everything else
+    res1, wall1, rows1 = one_call(1)
+    assert list(res.nsteps) == list(res1.nsteps) and list(res.measure["lml"]) == list(res1.measure["lml"])
     return {"workload": f"ranks {ranks[0]}..{ranks[-1]} on the headline matrix through vb_factorize_sharded, reference defaults "
                         f"(hyper updates on, Tol 1e-5), {world} process(es)",
-            "wall_s": t_wall, "call_s_slowest_process": max(q["call_s"] for q in rows),
-            "stepping_s_total": sum(q["stepping_s"] for q in rows), "setup_s_slowest_process": max(q["setup_s"] for q in rows),
+            "wall_s": wall, "units_in_flight_per_process": 4, "call_s_slowest_process": max(q["call_s"] for q in rows),
+            "one_unit_at_a_time": {"wall_s": wall1, "stepping_s_total": sum(q["stepping_s"] for q in rows1),
+                                   "setup_s_slowest_process": max(q["setup_s"] for q in rows1), "per_process": rows1},
             "iterations_by_rank": dict(zip([int(v) for v in res.ranks], [int(v) for v in res.nsteps])),
             "iterations_total": int(sum(res.nsteps)),
-            "best_rank_by_lml": int(res.ranks[int(np.argmax(res.measure["lml"]))]), "per_process": rows}
+            "best_rank_by_lml": int(res.ranks[int(np.argmax(res.measure["lml"]))]),
+            "per_process": [{k: q[k] for k in ("process", "call_s", "layouts_s", "units_s", "exchange_s", "ranks")} for q in rows]}
 
 
 def timed_repeats(fn, barrier, repeats=5, after=None):
