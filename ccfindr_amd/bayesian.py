@@ -415,7 +415,7 @@ def select_best(vb, ranks):
 
 
 def make_bundle(mat, ranks, nrun, verbose, initializer, Itmax, hyper_update, gamma_a, gamma_b, Tol,
-                hyper_update_n0, hyper_update_dn, fudge, unif_stop, seed, device, engine_factory=None):
+                hyper_update_n0, hyper_update_dn, fudge, unif_stop, seed, device, engine_factory=None, check_empty=True):
     """Argument handling and guards of reference R/bayesian.R:238-259."""
     if fudge is None:
         fudge = EPS                                                              # :238
@@ -424,7 +424,7 @@ def make_bundle(mat, ranks, nrun, verbose, initializer, Itmax, hyper_update, gam
     X = mat if isinstance(mat, CountMatrix) else CountMatrix(mat)
     # (a shell -- CountMatrix.shell, a sharded sweep's processes that do not hold X -- has no entries to check: the
     # process that holds them ran these guards and every process raises on its findings, ccfindr_amd.parallel)
-    nullr, nullc = (0, 0) if getattr(X, "is_shell", False) else X.empty_counts()   # :244-245
+    nullr, nullc = (0, 0) if (getattr(X, "is_shell", False) or not check_empty) else X.empty_counts()   # :244-245
     if nullr > 0:
         raise ValueError("Input matrix contains empty rows")
     if nullc > 0:

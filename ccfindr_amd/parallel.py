@@ -177,8 +177,9 @@ def vb_factorize_sharded(mat, ranks=2, nrun=1, verbose=0, initializer="random", 
         X = CountMatrix.shell(meta)
     n, m = int(meta[0]), int(meta[1])
     bundle = make_bundle(X if native else mat, ranks, nrun, verbose, initializer, Itmax, hyper_update, gamma_a, gamma_b, Tol,
-                         hyper_update_n0, hyper_update_dn, fudge, unif_stop, seed, device, engine_factory) \
-        if (native or mat is not None) else None
+                         hyper_update_n0, hyper_update_dn, fudge, unif_stop, seed, device, engine_factory,
+                         check_empty=not native) \
+        if (native or mat is not None) else None                   # (native: the guards ran above, on the holders, for everybody)
     if bundle is None:
         raise ValueError("an injected engine_factory needs the matrix on every process")
     tasks, costs = sweep_tasks(bundle["ranks"], nrun)
