@@ -18,8 +18,10 @@ repeat bracketed by a barrier + device synchronise; all five times are reported)
 `warmup_effective` = W + the settle steps below; `setup` = seconds of untimed set-up (ingestion of X, engine creation =
 the two tiled layouts + their upload, initial state + priming sweep, a second engine on the same matrix).
 The roofline figures of k_sweep come from HIP events around its launches, on the engine's stream, in the host-stepped
-pass (mean per repeat, median over the five repeats, all five in `kernel_ms_repeats`).  `roofline.traffic` is NOT measured in this run: it is the HBM byte count of the rocprofv3 --pmc passes kept
-under profiles/ (`traffic_source` names the file).
+pass (mean per repeat, median over the five repeats, all five in `kernel_ms_repeats`).  `roofline.traffic` is measured in the
+same run at N = 1: rank 0 starts two short CHILD runs of this file under `rocprofv3 --pmc` (FETCH_SIZE, then WRITE_SIZE; each
+its own pass, no trace domain beside --pmc) and takes 2 x FETCH_SIZE + WRITE_SIZE per k_sweep launch; if rocprofv3 is missing
+or a pass fails it falls back to the figure kept under profiles/ (`traffic_source` says which it was).
 
 CPU references timed in the same run, on rank 0 at N = 1: `cpu_baseline` = the oracle's stored-entries step with
 OpenMP on the box's cores (kind "port"); `cpu_reference_literal` = the oracle's LITERAL restatement of
@@ -282,6 +284,58 @@ def rank_sweep_sample(M, world, rank, local_rank, barrier, small=False):
             "per_process": [{k: q[k] for k in ("process", "call_s", "layouts_s", "units_s", "exchange_s", "ranks")} for q in rows]}
 
 
+def measure_sweep_traffic(timeout_s=300.0):
+    """HBM bytes per k_sweep launch measured IN THIS RUN, on this box: two child runs of this file under
+    `rocprofv3 --pmc` (FETCH_SIZE, then WRITE_SIZE: the TCC block cannot hold both in one pass; no trace domain beside
+    --pmc), a short headline-only workload each; bytes = 2 x FETCH_SIZE + WRITE_SIZE in KB -- the gfx950 correction of
+    /opt/skills/guides/MI355X_MICROARCH.md for a wide coalesced streaming read.  Returns (bytes, detail) or (None, reason);
+    never raises: a box without rocprofv3, a counter pass that fails or takes too long leaves the figure to the file under
+    profiles/.  BENCH_NO_TRAFFIC=1 skips it."""
+    import csv
+    import glob
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    if os.environ.get("BENCH_NO_TRAFFIC"):
+        return None, "skipped (BENCH_NO_TRAFFIC)"
+    tool = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not tool:
+        return None, "rocprofv3 not found"
+    means = {}
+    t_all = time.perf_counter()
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
+        env = dict(os.environ, BENCH_NO_SWEEP="1", BENCH_NO_TRAFFIC="1", TMPDIR="/tmp")
+        cmd = [tool, "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "pmc", "--", sys.executable,
+               os.path.abspath(__file__), "--steps", "24", "--warmup", "2", "--no-cpu", "--no-ml"]
+        try:
+            proc = subprocess.Popen(cmd, env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = proc.wait(timeout=timeout_s / 2)
+            except subprocess.TimeoutExpired:
+                os.killpg(proc.pid, signal.SIGKILL)          # exactly the group this call started
+                proc.wait()
+                shutil.rmtree(out, ignore_errors=True)
+                return None, f"the {counter} pass exceeded {timeout_s / 2:.0f} s"
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if rc != 0 or not files:
+                shutil.rmtree(out, ignore_errors=True)
+                return None, f"the {counter} pass ended with status {rc}"
+            vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(files[0]))
+                    if r["Counter_Name"] == counter and "k_sweep<" in r["Kernel_Name"]]
+            shutil.rmtree(out, ignore_errors=True)
+            if not vals:
+                return None, f"no k_sweep dispatch in the {counter} pass"
+            means[counter] = (sum(vals) / len(vals), len(vals))
+        except Exception as exc:                              # noqa: BLE001 -- the figure is optional, the bench line is not
+            shutil.rmtree(out, ignore_errors=True)
+            return None, f"{type(exc).__name__}: {exc}"
+    f, w = means["FETCH_SIZE"][0], means["WRITE_SIZE"][0]
+    return (2.0 * f + w) * 1024.0, {"FETCH_SIZE_KB_per_launch": f, "WRITE_SIZE_KB_per_launch": w,
+                                    "dispatches": means["FETCH_SIZE"][1], "seconds": time.perf_counter() - t_all}
+
+
 def timed_repeats(fn, barrier, repeats=5, after=None):
     """`repeats` x [barrier, fn(), barrier] -> list of seconds; `after()` runs outside the timed region of every repeat."""
     out = []
@@ -320,6 +374,7 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=4)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-ml", action="store_true", help="skip the ML-NMF side measurement")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the in-run rocprofv3 --pmc passes behind roofline.traffic")
     ap.add_argument("--rank", type=int, default=0, help="diagnostic: another rank on the same matrix (the metric is rank 10)")
     args = ap.parse_args()
 
@@ -526,13 +581,20 @@ def main():
         sweep_s = (sweep_ms / max(sweep_cnt, 1)) * 1e-3
         achieved = bytes_sweep / sweep_s / 1e9 if sweep_cnt else None
         info = base_eng.layout_info()
-        traffic, traffic_source = None, None
+        traffic, traffic_source, traffic_detail = None, None, None
+        if world == 1 and not args.small and args.rank == 0 and not args.no_traffic:
+            # measured in this run, on this box: two short child runs under rocprofv3 --pmc (the engine of THIS process is idle meanwhile)
+            traffic, traffic_detail = measure_sweep_traffic()
+            if traffic is not None:
+                traffic_source = ("measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE over two child runs of this "
+                                  "command (24 steps each), 2 x FETCH_SIZE + WRITE_SIZE per k_sweep launch")
         for tname in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):          # newest rocprofv3 --pmc summary kept under profiles/
             tpath = os.path.join(ROOT, "profiles", tname)
-            if os.path.exists(tpath) and not args.small and args.rank in (0, 10):
+            if traffic is None and os.path.exists(tpath) and not args.small and args.rank in (0, 10):
                 try:
                     traffic = json.load(open(tpath)).get("sweep_hbm_bytes_per_launch")
-                    traffic_source = f"profiles/{tname} (rocprofv3 --pmc passes of an earlier run of this command; not measured in this run)"
+                    traffic_source = (f"profiles/{tname} (rocprofv3 --pmc passes of an earlier run of this command; not measured in this run"
+                                      + (f": {traffic_detail}" if isinstance(traffic_detail, str) else "") + ")")
                     break
                 except Exception:
                     traffic = None
@@ -552,6 +614,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_sweep", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "traffic_source": traffic_source,
+                         "traffic_counters": traffic_detail if isinstance(traffic_detail, dict) else None,
                          "algorithmic_bytes_per_launch": bytes_sweep, "kernel_ms": sweep_s * 1e3,
                          "kernel_ms_repeats": per_repeat_ms,
                          "streamed_bytes_per_launch": info["stream_bytes_per_step"]},
