@@ -625,8 +625,10 @@ int launch_ml_update(vbnmf_engine *e, bool gene_side, int prior, double ga, doub
     MlFold fold{};
     if (foldp) fold = *foldp;
     const unsigned grid = fold.control_only ? 1 : (unsigned)e->ub;
+    static const int stage_allowed = [] { const char *v = getenv("VBNMF_NO_STAGE_IDS"); return (v && v[0] == '1') ? 0 : 1; }();
+    const int stage_ids = stage_allowed && S.n_tasks >= (int64_t)256 * grid ? 1 : 0;      // (as launch_update)
     switch (e->R) {
-#define X(RR) case RR: hipLaunchKernelGGL((k_ml_update<RR>), dim3(grid), dim3(kUpdateThreads), 0, e->stream, S.part, S.inv_ptr, S.inv_task, nmaj, e->r, other_bp, e->ub, prior, ga, gb, eps, f, bp, stop, fold); break;
+#define X(RR) case RR: hipLaunchKernelGGL((k_ml_update<RR>), dim3(grid), dim3(kUpdateThreads), 0, e->stream, S.part, S.inv_ptr, S.inv_task, nmaj, e->r, other_bp, e->ub, prior, ga, gb, eps, f, bp, stop, fold, stage_ids); break;
         VBNMF_FOR_EACH_R(X)
 #undef X
         default: return fail(VBNMF_ERR_BAD_ARG, "unsupported padded rank %d", e->R);

@@ -38,12 +38,28 @@ template <int R>
 __global__ __launch_bounds__(kUpdateThreads) void k_ml_update(
     const double *__restrict__ part, const int32_t *__restrict__ inv_ptr, const uint32_t *__restrict__ inv_task,
     int64_t nmaj, int r, const double *__restrict__ other_bp, int other_nb, int prior, double ga, double gb, double eps,
-    double *__restrict__ f, double *__restrict__ bp, const int32_t *__restrict__ stop, const MlFold fold)
+    double *__restrict__ f, double *__restrict__ bp, const int32_t *__restrict__ stop, const MlFold fold, int stage_ids)
 {
     constexpr int RB = kUpdateThreads / R;       // majors per pass
     __shared__ double s_other[R + 2];
     __shared__ double s_e[kUpdateThreads];
+    __shared__ uint32_t s_ids[kStageIds];
+    __shared__ int32_t s_ptr[kStagePtr];
     const int t = threadIdx.x;
+    // the block's stretch of the inverse index into LDS, first thing (as k_update, kernels.h)
+    const int64_t per0 = (nmaj + gridDim.x - 1) / gridDim.x;
+    const int64_t bm0 = (int64_t)blockIdx.x * per0, bm1 = min(nmaj, bm0 + per0);
+    int q_lo = 0;
+    bool staged = false;
+    if (stage_ids && !fold.control_only && bm0 < bm1 && bm1 - bm0 < kStagePtr) {
+        q_lo = inv_ptr[bm0];
+        const int q_hi = inv_ptr[bm1];
+        staged = q_hi - q_lo <= kStageIds;               // (block-uniform)
+        if (staged) {
+            for (int q = t; q <= (int)(bm1 - bm0); q += kUpdateThreads) s_ptr[q] = inv_ptr[bm0 + q];
+            for (int q = q_lo + t; q < q_hi; q += kUpdateThreads) s_ids[q - q_lo] = inv_task[q];
+        }
+    }
     if (fold.prev) {
         // ---- the folded control step: k_ml_control's arithmetic, statement by statement ----
         __shared__ double sH[R + 2];
@@ -112,7 +128,8 @@ __global__ __launch_bounds__(kUpdateThreads) void k_ml_update(
         for (int64_t M = m0 + row; M < m1; M += RB) {
             const size_t o = (size_t)M * R + k;
             if (k < r) {
-                const double s = task_sum(part, inv_task, inv_ptr[M], inv_ptr[M + 1], R, k);
+                const double s = staged ? task_sum_lds(part, s_ids, s_ptr[M - bm0] - q_lo, s_ptr[M - bm0 + 1] - q_lo, R, k)
+                                        : task_sum(part, inv_task, inv_ptr[M], inv_ptr[M + 1], R, k);
                 double up = f[o] * s;
                 if (prior) up = up + ga - 1.0;   // :11,20
                 double v = up / down;
