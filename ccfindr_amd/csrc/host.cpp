@@ -13,6 +13,7 @@
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/statvfs.h>
 #include <unistd.h>
 
 #include <chrono>
@@ -1541,6 +1542,14 @@ struct ShmSink : LayoutSink {
         int64_t off = kBlobHeaderWords * 8;
         for (int q = 0; q < kBlobArrays; q++) { off = align64(off); offs[q] = off; off += a[q].bytes; }
         total = align64(off) + 8;
+        {   // a memory file system that is full answers the WRITES with SIGBUS, not the ftruncate with an error: ask first
+            std::string dir = path.substr(0, path.find_last_of('/') == std::string::npos ? 0 : path.find_last_of('/'));
+            if (dir.empty()) dir = ".";
+            struct statvfs vs;
+            if (statvfs(dir.c_str(), &vs) == 0 && (double)vs.f_bavail * (double)vs.f_frsize < (double)total)
+                return fail(VBNMF_ERR_OOM, "%s has %.0f MB free, the layout needs %.0f MB", dir.c_str(),
+                            (double)vs.f_bavail * (double)vs.f_frsize / 1e6, (double)total / 1e6);
+        }
         const std::string part = path + ".part";
         const int fd = open(part.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
         if (fd < 0) return fail(VBNMF_ERR_BAD_ARG, "cannot create %s: %s", part.c_str(), strerror(errno));
