@@ -21,6 +21,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <new>
 #include <numeric>
 
@@ -75,17 +76,31 @@ void parallel_for(int64_t count, const std::function<void(int64_t, int64_t, int)
     int nt = max_threads > 0 ? max_threads : host_threads();
     if ((int64_t)nt > count) nt = (int)count;
     if (nt <= 1) { fn(0, count, 0); return; }
+    // An exception leaving a std::thread ends the process (std::terminate): a worker that runs out of memory hands its
+    // exception to the calling thread instead, which rethrows it once every worker has been joined -- the C ABI's entry
+    // points then turn it into VBNMF_ERR_OOM like any other allocation failure.
+    std::exception_ptr first;
+    std::mutex first_mu;
+    auto guarded = [&](int64_t b, int64_t e, int t) {
+        try {
+            fn(b, e, t);
+        } catch (...) {
+            std::lock_guard<std::mutex> g(first_mu);
+            if (!first) first = std::current_exception();
+        }
+    };
     std::vector<std::thread> th;
     th.reserve(nt);
     for (int t = 0; t < nt; t++) {
         int64_t b = count * t / nt, e = count * (t + 1) / nt;
         try {
-            th.emplace_back([&fn, b, e, t] { fn(b, e, t); });
+            th.emplace_back([&guarded, b, e, t] { guarded(b, e, t); });
         } catch (const std::system_error &) {            // thread limit reached: this piece runs here
-            fn(b, e, t);
+            guarded(b, e, t);
         }
     }
     for (auto &x : th) x.join();
+    if (first) std::rethrow_exception(first);
 }
 
 // ------------------------------------------------------------------ ingestion
