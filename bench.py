@@ -640,6 +640,23 @@ def main():
             k = min(len(cpu_lk), len(gpu_lk))
             if k:
                 out["elbo_rel_err_first_steps"] = max(abs(g / c - 1) for g, c in zip(gpu_lk[:k], cpu_lk[:k]))
+    # Everything below is a side measurement.  At N > 1 it involves collectives (tiny ones in the sweep's control plane, the
+    # library's all-reduce in the partitioned sample): it can only hang where a peer or the fabric does, so the headline
+    # (measured above, without any collective) is safe behind a watchdog that prints it, records the hang and leaves.
+    dog = None
+    if world > 1:
+        import threading
+
+        def give_up():
+            if rank == 0:
+                for key in ("rank_sweep", "cells_partitioned"):
+                    out.setdefault(key, {"error": "timed out (watchdog 600 s): a collective of this side measurement hung", "hang": True})
+                print(json.dumps(out), flush=True)
+            os._exit(3)
+
+        dog = threading.Timer(600.0, give_up)
+        dog.daemon = True
+        dog.start()
     # Config C4 beside the headline, at every N: the rank sweep through vb_factorize_sharded (no collective on its data path).
     rank_sweep = None
     if args.mode == "restarts" and args.rank == 0 and not os.environ.get("BENCH_NO_SWEEP"):
@@ -654,20 +671,6 @@ def main():
     # factorisation is run on the same N GPUs, so that the RCCL path of the library is measured on hardware too.  It can
     # only hang where the fabric does, so the headline line is safe behind a watchdog that prints it and leaves.
     if world > 1 and args.mode == "restarts" and not os.environ.get("BENCH_NO_CELLS"):
-        import threading
-
-        def give_up():
-            # a collective or the fabric hung: the headline (measured before, without any collective) is still
-            # printed, the hang is recorded in the line, and EVERY rank leaves with a failure status
-            if rank == 0:
-                out["cells_partitioned"] = {"error": "timed out (watchdog 420 s): the cell-partitioned RCCL sample hung",
-                                            "hang": True}
-                print(json.dumps(out), flush=True)
-            os._exit(3)
-
-        dog = threading.Timer(420.0, give_up)
-        dog.daemon = True
-        dog.start()
         try:
             eng.close()
             cp, times = cells_partitioned_sample(world, rank, local_rank, barrier, max(50, min(args.steps, 300)) if not args.small else 20,
@@ -689,6 +692,7 @@ def main():
         except Exception as exc:                                   # noqa: BLE001 -- the headline must still be printed
             if rank == 0:
                 out["cells_partitioned"] = {"error": f"{type(exc).__name__}: {exc}"}
+    if dog is not None:
         dog.cancel()
     if rank == 0:
         print(json.dumps(out), flush=True)
