@@ -82,3 +82,42 @@ def test_layouts_uploaded_ahead_of_the_first_engine_change_nothing():
     assert np.array_equal(outs[0][0], outs[1][0])
     for k in outs[0][1]:
         assert np.array_equal(outs[0][1][k], outs[1][1][k]), k
+
+
+def test_device_buffers_are_pooled_between_engines_and_trimmed_on_request():
+    """An engine's device buffers go to the library's pool when it is destroyed (a rank sweep creates one engine per unit and
+    every hipFree synchronises the device) and vbnmf_pool_trim returns them to the driver; results do not depend on whether
+    an engine's buffers are fresh or reused (the arrays the kernels read are written or cleared first)."""
+    import torch
+    import ccfindr_amd as C
+    from ccfindr_amd import synth
+    hy = {"aw": 1.0, "bw": 1.0, "ah": 1.0, "bh": 1.0}
+    X = synth.fill_empty(synth.simulate_data(800, [600, 700], alpha0=0.2, seed=23, depth=np.full(1300, 120)), seed=23)
+    n, m = X.shape
+    M = C.CountMatrix(X)
+    wh = {r: synth.random_state(n, m, r, hy, seed=r) for r in (12, 7)}
+    C.load().vbnmf_pool_trim()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+
+    def run(r):
+        eng = C.VBEngine(M, r)
+        eng.set_state(wh[r]["lw"], wh[r]["lh"], wh[r]["eh"])
+        out = eng.run(hy, Itmax=9, Tol=0.0, flags=(True,) * 4, history=True)
+        st = eng.get_state()
+        eng.close()
+        return out["history"], st
+
+    first = {r: run(r) for r in (12, 7)}                       # rank 7 reuses (larger) buffers rank 12 left behind
+    again = {r: run(r) for r in (7, 12)}                       # ... and now the other way round
+    for r in (12, 7):
+        assert np.array_equal(first[r][0], again[r][0])
+        for k in first[r][1]:
+            assert np.array_equal(first[r][1][k], again[r][1][k]), (r, k)
+    torch.cuda.synchronize()
+    held = free0 - torch.cuda.mem_get_info()[0]
+    assert held > 0                                            # something is waiting in the pool (the layouts' copy stays with M)
+    M.close()
+    C.load().vbnmf_pool_trim()
+    torch.cuda.synchronize()
+    assert abs(free0 - torch.cuda.mem_get_info()[0]) < 64 * 2**20
