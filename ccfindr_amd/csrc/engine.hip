@@ -2331,6 +2331,13 @@ int vbnmf_test_stream_sleep(vbnmf_engine *e, double seconds)
 namespace { uint64_t hash_bytes(const void *data, size_t bytes, uint64_t seed); }
 extern "C" {
 // Test hook (no device needed): the content hash of the stateless cache, for tests/test_cabi_symbols.py.
+#ifdef VBNMF_ABL_STAMPS                                       /* instrumented builds only (profiles/ubench/r04/update_stamps.sh) */
+int vbnmf_test_update_stamps(unsigned long long *out)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return VBNMF_ERR_HIP;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_upd_stamps), sizeof(unsigned long long) * 2 * kUpdateBlocks * 12) == hipSuccess ? VBNMF_OK : VBNMF_ERR_HIP;
+}
+#endif
 uint64_t vbnmf_test_hash_bytes(const void *data, int64_t bytes, uint64_t seed) { return (data && bytes >= 0) ? hash_bytes(data, (size_t)bytes, seed) : 0; }
 }
 

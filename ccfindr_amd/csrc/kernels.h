@@ -643,6 +643,13 @@ struct ControlFold {
     int32_t control_only;          // 1: the launch behind the last step (no update)
 };
 
+#ifdef VBNMF_ABL_STAMPS                                       /* instrumented builds only (profiles/ubench/r04/update_stamps.sh) */
+__device__ unsigned long long g_upd_stamps[2 * kUpdateBlocks * 12];
+#define UPD_STAMP(i) do { if (threadIdx.x == 0 && !fold.control_only) g_upd_stamps[((size_t)side * kUpdateBlocks + blockIdx.x) * 12 + (i)] = wall_clock64(); } while (0)
+#else
+#define UPD_STAMP(i) do { } while (0)
+#endif
+
 template <int R>
 __global__ __launch_bounds__(kUpdateThreads) void k_update(
     const double *__restrict__ acc, const int32_t *__restrict__ inv_ptr, const uint32_t *__restrict__ inv_task,
@@ -658,6 +665,7 @@ __global__ __launch_bounds__(kUpdateThreads) void k_update(
     __shared__ int32_t s_ptr[kStagePtr];
     int stopped = 0;
     const int t = threadIdx.x;
+    UPD_STAMP(0);
     // The block's stretch of the inverse index into LDS, first thing: two dependent global round trips (pointers, then
     // ids) that the prologue's own loads overlap with, instead of two per ROUND of every major's gather below.
     const int64_t per0 = (nmaj + gridDim.x - 1) / gridDim.x;
@@ -673,6 +681,7 @@ __global__ __launch_bounds__(kUpdateThreads) void k_update(
             for (int q = q_lo + t; q < q_hi; q += kUpdateThreads) s_ids[q - q_lo] = inv_task[q];
         }
     }
+    UPD_STAMP(1);
     if (fold.prev) {
         // ---- the folded control step (see ControlFold; the arithmetic is k_control's, statement by statement) ----
         __shared__ double sW[R + 2], s_hy[4];
@@ -684,12 +693,14 @@ __global__ __launch_bounds__(kUpdateThreads) void k_update(
         // column sums of the previous gene-side partials and of the cell-side ones: the latter are also rowSums(eh),
         // the `other` of this update
         bp_colsums2(fold.bpW_prev, other_bp, other_nb, R + 2, sW, s_other, kUpdateThreads);
+        UPD_STAMP(8);
         if (was_stopped) {                       // a step queued past the stop: the control block and this block's row of the
             if (blockIdx.x == 0 && t == 0) *fold.next = *pv;                  // gene-side partials travel on unchanged
             if (t < R + 2 && !fold.control_only) bp[(size_t)blockIdx.x * (R + 2) + t] = fold.bpW_prev[(size_t)blockIdx.x * (R + 2) + t];
             return;
         }
         const double data = block_sum(part, s_e);            // (two barriers: sW, s_other are complete behind it)
+        UPD_STAMP(9);
         if (t < 2) {                              // lanes 0 and 1: the two Newton recurrences of hyper_update side by side
             if (t == 0) for (int q = 0; q < 4; q++) s_hy[q] = pv->hyper[q];
             int reason = 0, it = pv->it;
@@ -739,6 +750,7 @@ __global__ __launch_bounds__(kUpdateThreads) void k_update(
                 }
             }
         }
+        UPD_STAMP(10);
         __syncthreads();
         if (fold.control_only) return;
         if (s_stop) {                            // the loop ends here: no update, the partials' row travels on (as above)
@@ -756,6 +768,7 @@ __global__ __launch_bounds__(kUpdateThreads) void k_update(
     if (stopped) return;
     __syncthreads();
     }
+    UPD_STAMP(2);
     if (ctl || fold.prev) {
         double psi_a, lg_a;
         dev_psi_lgamma(a, &psi_a, &lg_a);
@@ -768,6 +781,7 @@ __global__ __launch_bounds__(kUpdateThreads) void k_update(
     const double be = a / b + s_other[k < R ? k : 0];
     const double lbe = log(be);
     double ve = 0.0, vt = 0.0, vl = 0.0;
+    UPD_STAMP(3);
     if (row < RB) {
         for (int64_t M = m0 + row; M < m1; M += RB) {
             const size_t o = (size_t)M * R + k;
@@ -808,13 +822,16 @@ __global__ __launch_bounds__(kUpdateThreads) void k_update(
             }
         }
     }
+    UPD_STAMP(4);
     s_e[t] = ve; s_t[t] = vt; s_l[t] = vl;
     __syncthreads();
+    UPD_STAMP(5);
     constexpr int P2 = (RB <= 32) ? 32 : (RB <= 64) ? 64 : (RB <= 128) ? 128 : (RB <= 256) ? 256 : 512;
     for (int h = P2 / 2; h >= 1; h >>= 1) {
         if (row < h && row + h < RB) { s_e[t] += s_e[t + h * R]; s_t[t] += s_t[t + h * R]; s_l[t] += s_l[t + h * R]; }
         __syncthreads();
     }
+    UPD_STAMP(6);
     double *o = bp + (size_t)blockIdx.x * (R + 2);
     if (t < R) o[t] = s_e[t];
     if (t == 0) {
@@ -822,6 +839,7 @@ __global__ __launch_bounds__(kUpdateThreads) void k_update(
         for (int q = 0; q < R; q++) { st += s_t[q]; sl += s_l[q]; }
         o[R] = st; o[R + 1] = sl;
     }
+    UPD_STAMP(7);
 }
 
 // State load (set_state): ll = l*log(l) and the block partials of e's column sums, same

@@ -1,7 +1,7 @@
 #!/bin/bash
 # ab_lib.sh LIB [ranks]: the in-tree library against profiles/ubench/libs/LIB (VBNMF_LIB), same box, interleaved:
 # it/s by bench.py, then k_update by side from a rocprofv3 kernel trace.
-export BENCH_NO_SWEEP=1 TMPDIR=/tmp
+export BENCH_NO_SWEEP=1 BENCH_NO_TRAFFIC=1 TMPDIR=/tmp
 R=$PWD
 LIB=$R/profiles/ubench/libs/$1
 RANKS=${2:-"10 20"}
