@@ -233,6 +233,8 @@ struct vbnmf_engine {
     int ub = kUpdateBlocks;           // blocks of the update kernels (one per CU; VBNMF_UPDATE_BLOCKS for experiments)
     double *red = nullptr;            // [n*R | R+4]  (partitioned engines only use the first part)
     int64_t red_count = 0;
+    bool epart_in_red = false;        // partitioned engines: the evidence partials live behind red[red_count) (kEvSlots + 1 doubles:
+                                      // the second all-reduce of a device-driven step sends them as they are)
     double *red_g = nullptr;          // same shape: receive side of the all-reduce in a device-driven partitioned loop
     const double *red_in = nullptr;   // what the W update and the control kernel read: red (reduced in place by the
                                       // caller) or red_g (out of place, so that steps queued past the stop stay no-ops)
@@ -274,6 +276,13 @@ struct vbnmf_engine {
     double sweep_ms = 0.0;
     int64_t sweep_launches = 0;
 };
+
+// doubles behind `red` / `red_g`: the reduce buffer proper (red_count, what the host-stepped exchange carries) and, for a
+// partitioned engine, the evidence slots of the device-driven loop's second all-reduce (kEvSlots partials + sum lgamma(x+1))
+inline int64_t red_alloc_count(const vbnmf_engine *e)
+{
+    return e->red_count + ((e->partitioned && 2 * (int64_t)e->n_wg <= kEvSlots) ? kEvSlots + 1 : 0);
+}
 
 namespace {
 
@@ -832,7 +841,8 @@ void vbnmf_engine_destroy(vbnmf_engine *e)
     free_side(e->A); free_side(e->B);
     dev_free(e->lw); dev_free(e->llw); dev_free(e->ew); dev_free(e->dw);
     dev_free(e->lh); dev_free(e->llh); dev_free(e->eh); dev_free(e->dh);
-    dev_free(e->epart); dev_free(e->bpW); dev_free(e->bpH);
+    if (!e->epart_in_red) dev_free(e->epart);
+    dev_free(e->bpW); dev_free(e->bpH);
     dev_free(e->d_perm); dev_free(e->d_ids[0]); dev_free(e->d_ids[1]); dev_free(e->d_table); dev_free(e->svd_ws); dev_free(e->svd_status);
     dev_free(e->red); dev_free(e->red_g); dev_free(e->d_out);
     for (hipEvent_t ev : e->ev_ring) (void)hipEventDestroy(ev);
@@ -932,7 +942,8 @@ int vbnmf_engine_create_geom(const vbnmf_matrix *X, int64_t cb, int64_t ce, int6
         if ((rc = dev_upload(&e->logtab, tab))) return bail(rc);
         if ((rc = dev_alloc(&e->ctl, 1))) return bail(rc);
         const char *nf = getenv("VBNMF_NO_CONTROL_FOLD");
-        e->fold = !e->partitioned && !(nf && nf[0] == '1');
+        // (partitioned engines: the evidence partials of the two sweeps must fit the fixed slots of the second all-reduce)
+        e->fold = !(nf && nf[0] == '1') && (!e->partitioned || 2 * (int64_t)e->n_wg <= kEvSlots);
         if (e->fold) {
             if ((rc = dev_alloc(&e->ctl2, 2)) || (rc = dev_alloc(&e->bpW_alt, (size_t)kUpdateBlocks * (e->R + 2))) ||
                 (rc = dev_alloc(&e->bpH_alt, (size_t)kUpdateBlocks * (e->R + 2)))) return bail(rc);
@@ -946,10 +957,11 @@ int vbnmf_engine_create_geom(const vbnmf_matrix *X, int64_t cb, int64_t ce, int6
     e->red_count = (int64_t)nR + e->R + 4;
     if ((rc = dev_alloc(&e->lw, nR)) || (rc = dev_alloc(&e->llw, nR)) || (rc = dev_alloc(&e->ew, nR)) || (rc = dev_alloc(&e->dw, nR)) ||
         (rc = dev_alloc(&e->lh, mR)) || (rc = dev_alloc(&e->llh, mR)) || (rc = dev_alloc(&e->eh, mR)) || (rc = dev_alloc(&e->dh, mR)) ||
-        (rc = dev_alloc(&e->epart, 2 * (size_t)e->n_wg)) ||
         (rc = dev_alloc(&e->bpW, bpn)) || (rc = dev_alloc(&e->bpH, bpn)) ||
-        (rc = dev_alloc(&e->red, (size_t)e->red_count)) || (rc = dev_alloc(&e->d_out, 8)))
+        (rc = dev_alloc(&e->red, (size_t)red_alloc_count(e))) || (rc = dev_alloc(&e->d_out, 8)))
         return bail(rc);
+    if (e->partitioned && 2 * (int64_t)e->n_wg <= kEvSlots) { e->epart = e->red + e->red_count; e->epart_in_red = true; }
+    else if ((rc = dev_alloc(&e->epart, 2 * (size_t)e->n_wg))) return bail(rc);
     hipError_t he;
     if ((he = hipHostMalloc((void **)&e->h_out, kHostOut * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess ||
         (he = hipHostGetDevicePointer((void **)&e->h_out_dev, e->h_out, 0)) != hipSuccess ||
@@ -965,8 +977,10 @@ int vbnmf_engine_create_geom(const vbnmf_matrix *X, int64_t cb, int64_t ce, int6
     }
     if ((he = hipMemset(e->ew, 0, nR * sizeof(double))) != hipSuccess || (he = hipMemset(e->dw, 0, nR * sizeof(double))) != hipSuccess ||
         (he = hipMemset(e->dh, 0, mR * sizeof(double))) != hipSuccess || (he = hipMemset(e->bpW, 0, bpn * sizeof(double))) != hipSuccess ||
-        (he = hipMemset(e->bpH, 0, bpn * sizeof(double))) != hipSuccess || (he = hipMemset(e->red, 0, (size_t)e->red_count * sizeof(double))) != hipSuccess)
+        (he = hipMemset(e->bpH, 0, bpn * sizeof(double))) != hipSuccess || (he = hipMemset(e->red, 0, (size_t)red_alloc_count(e) * sizeof(double))) != hipSuccess)
         return bail(fail(VBNMF_ERR_HIP, "hipMemset failed: %s", hipGetErrorString(he)));
+    if (e->epart_in_red && (he = hipMemcpy(e->red + e->red_count + kEvSlots, &e->lgx, sizeof(double), hipMemcpyHostToDevice)) != hipSuccess)
+        return bail(fail(VBNMF_ERR_HIP, "hipMemcpy failed: %s", hipGetErrorString(he)));
     *out = e;
     return VBNMF_OK;
 }
@@ -1235,11 +1249,14 @@ int ensure_history(vbnmf_engine *e, size_t doubles)
 }
 
 // What a partitioned engine needs beside its own stream: the stream the all-reduces go on, the receive buffer, and
-// a ring of events (four per step, steps queued at most three batches of eight ahead: 160 never wraps onto a pending one).
+// a ring of events (five per step, steps queued at most three batches of eight ahead: 160 never wraps onto a pending one).
 int ensure_comm_resources(vbnmf_engine *e)
 {
     if (!e->cstream) HIPCHECK(hipStreamCreateWithFlags(&e->cstream, hipStreamNonBlocking));
-    if (!e->red_g) { if (int rc = dev_alloc(&e->red_g, (size_t)e->red_count)) return rc; }
+    if (!e->red_g) {
+        if (int rc = dev_alloc(&e->red_g, (size_t)red_alloc_count(e))) return rc;
+        HIPCHECK(hipMemset(e->red_g, 0, (size_t)red_alloc_count(e) * sizeof(double)));
+    }
     while (e->ev_ring.size() < 160) {
         hipEvent_t ev;
         HIPCHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -1294,7 +1311,9 @@ int group_tables(vbnmf_comm *c)
     for (int p = 0; p < P; p++) {
         vbnmf_engine *e = c->members[p];
         if (int rc = ensure_comm_resources(e)) return rc;
-        const size_t off = (size_t)e->n * e->R + e->R + 2;
+        // second exchange of a device-driven step: the evidence slots behind the reduce buffer (control step folded into
+        // the next update), or the two doubles k_tail_data forms (VBNMF_NO_CONTROL_FOLD=1)
+        const size_t off = e->fold ? (size_t)e->red_count : (size_t)e->n * e->R + e->R + 2;
         sb[p] = e->red; rb[p] = e->red_g; ss[p] = e->red + off; rs[p] = e->red_g + off;
     }
     dev_free(c->d_send_big); dev_free(c->d_send_small); dev_free(c->d_recv_big); dev_free(c->d_recv_small);
@@ -1312,14 +1331,16 @@ int group_tables(vbnmf_comm *c)
 }
 
 // One step of the device-driven VB loop, queued on every engine of the group.
-//   unpartitioned : k_update(W) k_update(H) k_sweep(both sides) k_control
-//   partitioned   : k_update(W <- reduced statistics) k_update(H) | gene-side sweep | event -> comm stream: k_pack, k_tail_h
+//   unpartitioned : k_update(W, + the control step of the previous sweep) k_update(H) k_sweep(both sides)
+//   partitioned   : k_update(W <- reduced statistics, + the control step of the previous sweeps) k_update(H) | gene-side sweep
+//                   | k_pack_tail (main stream for an RCCL rank, comm stream for a local group) | event
 //                   -> comm stream: all-reduce [swsum | rowSum(eh) | 2 scalars]     (RCCL, or k_group_sum)
-//                   || main stream: cell-side sweep, k_tail_data | event
-//                   -> comm stream: all-reduce [data term | sum lgamma(x+1)] | event -> main stream: k_control
-// so the n*R-double exchange travels while the cell-side sweep runs and only the two-double
-// one sits between the sweep and the control kernel.  The all-reduces are out of place (red -> red_g): steps queued
-// past the stop leave `red` untouched, so repeating them reproduces the same sums.
+//                   || main stream: cell-side sweep
+//                   -> main stream: all-reduce [evidence slots | sum lgamma(x+1)]   (behind an event after the first one)
+// so the n*R-double exchange travels while the cell-side sweep runs and only the small one sits
+// between the sweep and the next update.  (VBNMF_NO_CONTROL_FOLD=1: k_tail_data, a two-double exchange and k_control
+// close the step instead.)  The all-reduces are out of place (red -> red_g): steps queued past the stop leave `red`
+// untouched, so repeating them reproduces the same sums.
 int queue_vb_step(const LoopGroup &G, double fudge, bool hist, int max_it)
 {
     if (!G.comm && G.e[0]->fold) {
@@ -1360,17 +1381,52 @@ int queue_vb_step(const LoopGroup &G, double fudge, bool hist, int max_it)
     const int P = G.count;
     vbnmf_engine *L = G.e[0];                                  // leader: owner of the comm stream used by a local group
     const int64_t nbig = L->n * L->R + L->R + 2;
+    const bool fold = L->fold;
+    static const bool small_on_comm = [] { const char *v = getenv("VBNMF_SMALL_ON_COMM"); return v && v[0] == '1'; }();   // (see the second exchange below)
     hipEvent_t evA[64], evB[64];
+    ControlFold last{};                                        // (fold) the control-only launch behind step max_it
     for (int p = 0; p < P; p++) {
         vbnmf_engine *e = G.e[p];
-        int rc = launch_update(e, true, 0, 0, fudge, e->ctl);
-        if (!rc) rc = launch_update(e, false, 0, 0, fudge, e->ctl);
+        int rc;
+        if (fold) {
+            // k_update(W <- reduced statistics, with the control step of the PREVIOUS sweeps folded in: no k_control launch
+            // and no k_tail_data between the second all-reduce and the next update -- that exchange carries the evidence
+            // partials of the two sweeps as they are, element-wise, and the fold adds them up)
+            const int t = ++e->fold_step;
+            ControlFold f{};
+            f.prev = e->ctl2 + ((t - 1) & 1); f.next = e->ctl2 + (t & 1);
+            f.bpW_prev = e->bpW; f.nbW = e->ub;
+            std::swap(e->bpW, e->bpW_alt);
+            f.tail_in = e->red_g + (size_t)e->n * e->R;
+            f.epart = e->red_g + e->red_count; f.nepart = kEvSlots;
+            f.lgx_in = e->red_g + e->red_count + kEvSlots;
+            f.lgx = 0.0; f.n = (double)e->n; f.m_global = (double)e->m_global;
+            f.history = hist && p == 0 ? e->h_hist_dev : nullptr; f.out_host = e->h_out_dev;
+            f.do_control = t > 1 ? 1 : 0;
+            rc = launch_update(e, true, 0, 0, fudge, nullptr, &f);
+            e->stop_ptr = &f.next->stop;
+            if (!rc) rc = launch_update(e, false, 0, 0, fudge, f.next);
+            if (t == max_it) {
+                last = f;
+                last.prev = f.next; last.next = e->ctl2 + ((t + 1) & 1);
+                last.do_control = 1; last.control_only = 1;
+            }
+        } else {
+            rc = launch_update(e, true, 0, 0, fudge, e->ctl);
+            if (!rc) rc = launch_update(e, false, 0, 0, fudge, e->ctl);
+        }
         if (!rc) rc = launch_vb_side(e, true);
         if (rc) return rc;
-        // The gene-side partials are packed into the send buffer on the engine's COMM stream, not on the main one: k_pack
-        // (a gather of 100 MB of task rows at C5: 26 us) and k_tail_h hold no LDS and run beside the cell-side sweep, which
-        // does not depend on them -- only the all-reduce does, and it follows them in comm-stream order.
-        static const bool pack_on_main = [] { const char *v = getenv("VBNMF_PACK_ON_MAIN"); return v && v[0] == '1'; }();   // A/B switch
+        const int32_t *stop = e->stop_ptr ? e->stop_ptr : &e->ctl->stop;
+        // Where the gene-side partials are packed into the send buffer (k_pack: a gather of 100 MB of task rows at C5, 26 us
+        // with the chip to itself; k_tail_h).  Ranks that exchange through RCCL pack on the MAIN stream, between the two
+        // sweeps: the all-reduce of n * R doubles must travel WHILE the cell-side sweep runs, and a k_pack queued beside that
+        // sweep is starved by its persistent workgroups (profiles/r04_c5_step_timeline.txt: 168 us, ending after the sweep
+        // -- the collective would start when the sweep is over).  The partitions of a local group share one GPU and
+        // their exchange is a 5 us kernel: there the pack goes to the comm stream, where the other partitions' kernels fill
+        // the chip around it (-12 us per partition step on the same box).  VBNMF_PACK_ON_MAIN=1 / 0 forces either.
+        static const int pack_env = [] { const char *v = getenv("VBNMF_PACK_ON_MAIN"); return !v ? -1 : (v[0] == '1' ? 1 : 0); }();
+        const bool pack_on_main = pack_env >= 0 ? pack_env == 1 : c->kind == 0;
         hipStream_t ps = pack_on_main ? e->stream : e->cstream;
         if (!pack_on_main) {
             hipEvent_t evS = next_event(e);
@@ -1378,9 +1434,8 @@ int queue_vb_step(const LoopGroup &G, double fudge, bool hist, int max_it)
             HIPCHECK(hipStreamWaitEvent(e->cstream, evS, 0));
         }
         const int64_t cnt = e->n * e->R;
-        hipLaunchKernelGGL(k_pack, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ps, e->A.part, e->A.inv_ptr, e->A.inv_task, e->n, e->R, e->red);
-        HIPCHECK(hipGetLastError());
-        hipLaunchKernelGGL(k_tail_h, dim3(1), dim3(1024), 0, ps, e->bpH, e->ub, e->R, e->red + cnt, &e->ctl->stop);
+        hipLaunchKernelGGL(k_pack_tail, dim3((unsigned)((cnt + 255) / 256) + 1), dim3(256), 0, ps, e->A.part, e->A.inv_ptr, e->A.inv_task, e->n, e->R, e->red,
+                           e->bpH, e->ub, stop);
         HIPCHECK(hipGetLastError());
         evA[p] = next_event(e);
         HIPCHECK(hipEventRecord(evA[p], ps));
@@ -1396,25 +1451,52 @@ int queue_vb_step(const LoopGroup &G, double fudge, bool hist, int max_it)
     for (int p = 0; p < P; p++) {
         vbnmf_engine *e = G.e[p];
         if (int rc = launch_vb_side(e, false)) return rc;
-        hipLaunchKernelGGL(k_tail_data, dim3(1), dim3(1024), 0, e->stream, e->epart, 2 * (int64_t)e->n_wg, e->lgx, e->red + nbig, &e->ctl->stop);
-        HIPCHECK(hipGetLastError());
-        evB[p] = next_event(e);
-        HIPCHECK(hipEventRecord(evB[p], e->stream));
+        if (!fold) {
+            hipLaunchKernelGGL(k_tail_data, dim3(1), dim3(1024), 0, e->stream, e->epart, 2 * (int64_t)e->n_wg, e->lgx, e->red + nbig, &e->ctl->stop);
+            HIPCHECK(hipGetLastError());
+        }
+        if (small_on_comm || p > 0) {                            // (an event costs the stream a barrier packet: only where another stream waits on it)
+            evB[p] = next_event(e);
+            HIPCHECK(hipEventRecord(evB[p], e->stream));
+        }
     }
-    hipEvent_t evD = next_event(L);
+    // The second exchange sits between the cell-side sweep and the next update on every rank's critical path, so it is
+    // issued on the leader's MAIN stream: no hand-over to the comm stream and back (two cross-queue waits, microseconds
+    // each, for a collective of a few KB).  It follows the first exchange through an event recorded behind it on the comm
+    // stream -- long satisfied by then -- so the two collectives of a step never overlap and every rank issues them in the
+    // same order.  VBNMF_SMALL_ON_COMM=1 puts it back on the comm stream (A/B switch).
+    hipStream_t ss = small_on_comm ? L->cstream : L->stream;
+    if (!small_on_comm) {
+        hipEvent_t evBig = next_event(L);
+        HIPCHECK(hipEventRecord(evBig, L->cstream));
+        HIPCHECK(hipStreamWaitEvent(L->stream, evBig, 0));
+    }
+    const bool need_evD = small_on_comm || P > 1;
+    hipEvent_t evD = need_evD ? next_event(L) : nullptr;
     if (c->kind == 0) {
-        HIPCHECK(hipStreamWaitEvent(L->cstream, evB[0], 0));
-        if (int rc = rccl_check(rccl_api().AllReduce(L->red + nbig, L->red_g + nbig, 2, ncclDouble, ncclSum, c->nc, L->cstream), "ncclAllReduce")) return rc;
+        if (small_on_comm) HIPCHECK(hipStreamWaitEvent(L->cstream, evB[0], 0));
+        const int64_t off = fold ? L->red_count : nbig, cnt = fold ? kEvSlots + 1 : 2;
+        if (int rc = rccl_check(rccl_api().AllReduce(L->red + off, L->red_g + off, (size_t)cnt, ncclDouble, ncclSum, c->nc, ss), "ncclAllReduce")) return rc;
     } else {
-        for (int p = 0; p < P; p++) HIPCHECK(hipStreamWaitEvent(L->cstream, evB[p], 0));
-        hipLaunchKernelGGL(k_group_sum, dim3(1), dim3(256), 0, L->cstream, c->d_send_small, c->d_recv_small, P, (int64_t)2);
+        for (int p = small_on_comm ? 0 : 1; p < P; p++) HIPCHECK(hipStreamWaitEvent(ss, evB[p], 0));
+        const int64_t cnt = fold ? kEvSlots + 1 : 2;
+        hipLaunchKernelGGL(k_group_sum, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ss, c->d_send_small, c->d_recv_small, P, cnt);
         HIPCHECK(hipGetLastError());
     }
-    HIPCHECK(hipEventRecord(evD, L->cstream));
+    if (need_evD) HIPCHECK(hipEventRecord(evD, ss));
     for (int p = 0; p < P; p++) {
         vbnmf_engine *e = G.e[p];
-        HIPCHECK(hipStreamWaitEvent(e->stream, evD, 0));
-        if (int rc = launch_control(e, hist && p == 0 ? e->h_hist_dev : nullptr, true)) return rc;
+        if (need_evD && e->stream != ss) HIPCHECK(hipStreamWaitEvent(e->stream, evD, 0));
+        if (!fold) { if (int rc = launch_control(e, hist && p == 0 ? e->h_hist_dev : nullptr, true)) return rc; }
+        else if (last.control_only) {                           // behind the last step of the run: the control step alone
+            ControlFold g = last;
+            g.prev = e->ctl2 + (e->fold_step & 1); g.next = e->ctl2 + ((e->fold_step + 1) & 1);
+            g.bpW_prev = e->bpW; g.nbW = e->ub;
+            g.tail_in = e->red_g + (size_t)e->n * e->R;
+            g.epart = e->red_g + e->red_count; g.lgx_in = e->red_g + e->red_count + kEvSlots;
+            g.history = hist && p == 0 ? e->h_hist_dev : nullptr; g.out_host = e->h_out_dev;
+            if (int rc = launch_update(e, true, 0, 0, fudge, nullptr, &g)) return rc;
+        }
     }
     return VBNMF_OK;
 }
@@ -1505,7 +1587,7 @@ int run_group(const LoopGroup &G, double *hyper, double fudge, int32_t max_it, d
         timing[p] = e->timing;
         e->timing = false;                                         // event pairs cannot follow launches queued ahead
         e->ev_recorded = false; e->ev2_recorded = false;
-        hipLaunchKernelGGL(k_ctl_init, dim3(1), dim3(1), 0, e->stream, (!G.comm && e->fold) ? e->ctl2 : e->ctl, c);
+        hipLaunchKernelGGL(k_ctl_init, dim3(1), dim3(1), 0, e->stream, e->fold ? e->ctl2 : e->ctl, c);
         e->fold_step = 0;
         if (G.comm) {                                              // the reduced statistics of the loaded state
             e->red_in = e->red_g;
@@ -1538,7 +1620,7 @@ int run_group(const LoopGroup &G, double *hyper, double fudge, int32_t max_it, d
     hipError_t he = hipGetLastError();
     if (he != hipSuccess) return cleanup(fail(VBNMF_ERR_HIP, "loading the loop control block failed: %s", hipGetErrorString(he)));
 
-    int rc = drive_loop(e0, max_it, !G.comm && e0->fold, [&]() { return queue_vb_step(G, fudge, history != nullptr, max_it); });
+    int rc = drive_loop(e0, max_it, e0->fold, [&]() { return queue_vb_step(G, fudge, history != nullptr, max_it); });
     if (rc) return cleanup(rc);
     for (int p = 0; p < G.count; p++) {
         he = hipStreamSynchronize(G.e[p]->stream);

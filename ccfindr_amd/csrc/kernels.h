@@ -641,7 +641,18 @@ struct ControlFold {
     double *history, *out_host;
     int32_t do_control;            // 0: first step of a run (nothing to evaluate yet: next = prev)
     int32_t control_only;          // 1: the launch behind the last step (no update)
+    // Cell-partitioned engines (the update is the dense one, on the all-reduced statistics): the cell side's sums come
+    // all-reduced too -- tail_in = [rowSum(eh)_k | sum H-terms | sum log lh] (R + 2 doubles) --, epart / nepart are the
+    // ELEMENT-WISE all-reduced evidence partials of every partition's sweeps (kEvSlots doubles, zero beyond the workgroups
+    // in use) and lgx_in points at the all-reduced sum lgamma(x + 1); bpW_prev (nbW rows) is replicated.
+    const double *tail_in;
+    const double *lgx_in;
+    int32_t nbW;
 };
+
+// Evidence partials of a partition's two sweeps as they travel through the all-reduce of a device-driven partitioned
+// loop: a fixed number of slots (the same on every rank whatever its workgroup count), then sum lgamma(x + 1).
+constexpr int kEvSlots = 1024;
 
 #ifdef VBNMF_ABL_STAMPS                                       /* instrumented builds only (profiles/ubench/r04/update_stamps.sh) */
 __device__ unsigned long long g_upd_stamps[2 * kUpdateBlocks * 12];
@@ -692,7 +703,12 @@ __global__ __launch_bounds__(kUpdateThreads) void k_update(
         if (fold.do_control) for (int64_t q = t; q < fold.nepart; q += kUpdateThreads) part += fold.epart[q];
         // column sums of the previous gene-side partials and of the cell-side ones: the latter are also rowSums(eh),
         // the `other` of this update
-        bp_colsums2(fold.bpW_prev, other_bp, other_nb, R + 2, sW, s_other, kUpdateThreads);
+        if (fold.tail_in) {
+            bp_colsums(fold.bpW_prev, fold.nbW, R + 2, sW, kUpdateThreads);
+            if (t < R + 2) s_other[t] = fold.tail_in[t];
+        } else {
+            bp_colsums2(fold.bpW_prev, other_bp, other_nb, R + 2, sW, s_other, kUpdateThreads);
+        }
         UPD_STAMP(8);
         if (was_stopped) {                       // a step queued past the stop: the control block and this block's row of the
             if (blockIdx.x == 0 && t == 0) *fold.next = *pv;                  // gene-side partials travel on unchanged
@@ -709,7 +725,8 @@ __global__ __launch_bounds__(kUpdateThreads) void k_update(
             if (fold.do_control) {
                 double cross = 0.0, sew = 0.0, seh = 0.0;
                 for (int k = 0; k < r; k++) { cross += sW[k] * s_other[k]; sew += sW[k]; seh += s_other[k]; }
-                const double U = -cross - data - fold.lgx + sW[R] + s_other[R];
+                const double lgx = fold.lgx_in ? *fold.lgx_in : fold.lgx;
+                const double U = -cross - data - lgx + sW[R] + s_other[R];
                 lkh = U / (fold.n * fold.m_global);
                 st[0] = sW[R + 1] / (fold.n * r); st[1] = s_other[R + 1] / (fold.m_global * r);
                 st[2] = sew / (fold.n * r); st[3] = seh / (fold.m_global * r);
@@ -884,6 +901,24 @@ __global__ __launch_bounds__(256) void k_pack(const double *__restrict__ part, c
                                               const uint32_t *__restrict__ inv_task, int64_t nmaj, int R,
                                               double *__restrict__ out)
 {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= nmaj * R) return;
+    const int64_t M = e / R;
+    const int k = (int)(e - M * R);
+    out[e] = task_sum(part, inv_task, inv_ptr[M], inv_ptr[M + 1], R, k);
+}
+
+// k_pack and k_tail_h in one launch (the device-driven partitioned loop): one extra block forms the cell side's column sums.
+__global__ __launch_bounds__(256) void k_pack_tail(const double *__restrict__ part, const int32_t *__restrict__ inv_ptr,
+                                                   const uint32_t *__restrict__ inv_task, int64_t nmaj, int R,
+                                                   double *__restrict__ out, const double *__restrict__ bpH, int nbH,
+                                                   const int32_t *__restrict__ stop)
+{
+    if (blockIdx.x == gridDim.x - 1) {
+        if (stop && *stop) return;                         // (as k_tail_h: steps queued past the stop leave the tail as it is)
+        bp_colsums(bpH, nbH, R + 2, out + nmaj * R, 256);
+        return;
+    }
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= nmaj * R) return;
     const int64_t M = e / R;

@@ -14,6 +14,8 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--rccl", action="store_true", help="a ONE-rank RCCL communicator instead of the local group of one: the schedule "
+                    "an RCCL rank runs (k_pack between the sweeps, collectives by librccl), with nothing to exchange")
     args = ap.parse_args()
     import torch
     import bench
@@ -25,21 +27,27 @@ def main():
     cols = (0, m // P)
     hy = {"aw": 1.0, "bw": 1.0, "ah": 1.0, "bh": 1.0}
     wh = synth.random_state(n, m, r, hy, seed=1005)
-    comm = C.Communicator.local(1)
+    comm = C.Communicator.rccl(C.Communicator.unique_id(), 1, 0, 0) if args.rccl else C.Communicator.local(1)
     eng = C.VBEngine(M, r, cols=cols, m_global=m)
     eng.attach_comm(comm)
     eng.set_state(wh["lw"], wh["lh"][:, cols[0]:cols[1]], wh["eh"][:, cols[0]:cols[1]])
-    comm.state_finish()
-    comm.run(hy, Itmax=50, Tol=0.0, flags=(False,) * 4)
+    if args.rccl:                              # an RCCL communicator is driven through its engine
+        eng.allreduce(); eng.state_finish()
+        run = eng.run
+    else:
+        comm.state_finish()
+        run = comm.run
+    run(hy, Itmax=50, Tol=0.0, flags=(False,) * 4)
     ts = []
     for _ in range(3):
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        comm.run(hy, Itmax=args.steps, Tol=0.0, flags=(False,) * 4)
+        run(hy, Itmax=args.steps, Tol=0.0, flags=(False,) * 4)
         torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) / args.steps)
     info = eng.layout_info()
     S = X.tocsc()
     nnz_local = int(S.indptr[cols[1]] - S.indptr[cols[0]])
     out = {"workload": f"C5 partition 1 of {P}: {n} x {cols[1] - cols[0]} of {m} cells, nnz {nnz_local}, rank {r}, alone on the GPU",
+           "communicator": "rccl, one rank" if args.rccl else "local group of one",
            "cell_order": os.environ.get("VBNMF_CELL_ORDER", "auto"), "ms_per_step": 1e3 * float(np.median(ts)),
            "tasks_gene": info["tasks_gene_side"], "tasks_cell": info["tasks_cell_side"]}
     print(json.dumps(out), flush=True)

@@ -143,3 +143,41 @@ def test_rccl_communicator_one_rank_device_loop():
     lkh, _ = part.step_finish()
     assert abs(2.0 * lkh / whole.step(HY)[0] - 1) <= 1e-10
     part.close(); whole.close(); comm.close()
+
+
+@pytest.mark.parametrize("tol,itmax", [(0.0, 23), (2e-4, 400)])
+def test_partitioned_control_fold_equals_the_separate_control_kernel(tol, itmax, monkeypatch):
+    """Partitioned engines fold the control step into the next step's gene-side update too (the second exchange of a step
+    carries the sweeps' evidence partials element-wise instead of the two doubles k_tail_data formed; no k_control launch).
+    VBNMF_NO_CONTROL_FOLD=1 (read when an engine is created) restores the separate kernels: same steps, same stop, the same
+    factors to rounding -- the evidence is summed over partitions first and over workgroups second, not the other way round."""
+    import ccfindr_amd as C
+    from ccfindr_amd import synth
+    from ccfindr_amd.parallel import cell_partition
+    n, m, r, P = 260, 430, 7, 3
+    X = _matrix(n, m, 91)
+    wh = synth.random_state(n, m, r, HY, seed=8)
+    M = C.CountMatrix(X)
+    kw = dict(Itmax=itmax, Tol=tol, n0=10, dn=1, flags=(True,) * 4, history=True)
+    out = {}
+    for mode in ("fold", "separate"):
+        if mode == "separate":
+            monkeypatch.setenv("VBNMF_NO_CONTROL_FOLD", "1")
+        else:
+            monkeypatch.delenv("VBNMF_NO_CONTROL_FOLD", raising=False)
+        comm, parts = _group(M, r, cell_partition(m, P), m, wh)
+        res = comm.run(HY, **kw)
+        again = comm.run(HY, **dict(kw, Itmax=3, Tol=0.0))            # a second run on the same engines starts from the state the first left
+        out[mode] = (res, again, [p.get_state() for p in parts])
+        for p in parts:
+            p.close()
+        comm.close()
+    (a, a2, sa), (b, b2, sb) = out["fold"], out["separate"]
+    assert a["it"] == b["it"] and a["reason"] == b["reason"] == (4 if tol == 0.0 else 2)
+    if tol > 0.0:
+        assert 10 < a["it"] < itmax
+    assert relerr(a["history"], b["history"]) <= 1e-11
+    assert a2["it"] == b2["it"] == 3 and relerr(a2["history"], b2["history"]) <= 1e-11
+    for x, y in zip(sa, sb):
+        for k in x:
+            assert relerr(x[k], y[k]) <= 1e-10, k
