@@ -124,7 +124,7 @@ def main():
         p.close()
 
     # The same partitions under the DEVICE-DRIVEN group loop (vbnmf_group_run: gene-side sweep, k_pack, the n x r sum on a
-    # second stream beside the cell-side sweep, the two-double sum, k_control -- all queued from C++): the P partitions
+    # second stream beside the cell-side sweep, the small sum of the evidence partials, the folded control step -- all queued from C++): the P partitions
     # share this one GPU, so a group step is P partition steps back to back; per partition = group step / P.
     comm = C.Communicator.local(P)
     parts = [C.VBEngine(M, r, cols=c, m_global=m) for c in cuts]

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """tests/manual_rccl_stress.py (run by hand through gpurun) -- the library's multi-rank RCCL protocol under load: P processes
 on the one GPU through the librccl stand-in (tests/fake_rccl, VBNMF_RCCL_LIB), a mid-size matrix, REPS device-driven runs of
-STEPS steps each with hyper-parameter updates on (every step queues two collectives on the comm stream and cycles the event
-ring; k_pack / k_tail_h run on the comm stream beside the cell-side sweep), then a convergence run.  Every run's history
+STEPS steps each with hyper-parameter updates on (every step queues two collectives -- the n x r one on the comm stream beside
+the cell-side sweep, the evidence slots on the main stream behind it -- and cycles the event ring), then a convergence run.  Every run's history
 must be identical on all ranks and equal to the single engine's to 1e-10; the gene-side state bit-identical across ranks.
 Writes gpurun_out/rccl_stress.json.      python tests/manual_rccl_stress.py [--procs 2] [--reps 6] [--steps 400]"""
 import argparse

@@ -1,6 +1,6 @@
 """The device-driven loop of cell-partitioned engines (vbnmf_engine_run with a communicator, vbnmf_group_run):
-per step the gene-side sweep, k_pack, the n x r all-reduce on a second stream beside the cell-side sweep, the two-double
-all-reduce, k_control -- all queued from C++ (reference loop: R/bayesian.R:337-352; exchange: SURVEY.md section 8e).
+per step the gene-side sweep, k_pack, the n x r all-reduce on a second stream beside the cell-side sweep, the small
+all-reduce of the evidence partials, the control step folded into the next update -- all queued from C++ (reference loop: R/bayesian.R:337-352; exchange: SURVEY.md section 8e).
 
 ONE test GPU, so the multi-partition runs use a local group (partition engines side by side in this process, the sum
 a kernel in partition order) and the RCCL path runs with one rank; both must reproduce the single engine."""
