@@ -227,7 +227,8 @@ def cells_partitioned_sample(world, rank, local_rank, barrier, steps, small=Fals
            "collective": ("library communicator: " + (os.environ.get("VBNMF_RCCL_LIB") and "stand-in named by VBNMF_RCCL_LIB (rehearsal)" or "RCCL"))
                          if eng.native else "torch.distributed",
            "scaling": "strong", "steps": steps, "repeats_ms_per_step": [1e3 * t / steps for t in times],
-           "allreduce_bytes_per_step": 8 * (n * r + r + 4), "allreduce_ms": ar_ms, "lkh_last": lkh_last,
+           "allreduce_bytes_per_step": 8 * (n * r + r + 2) + 8 * 1025,      # [sw | rowSums(eh) | 2] beside the sweep + the evidence slots behind it
+            "allreduce_ms": ar_ms, "lkh_last": lkh_last,
            "per_gpu": {"cells": m_local, "nnz": nnz_local, "algorithmic_bytes_per_step": bytes_gpu, "flops_per_step": flops_gpu}}
     eng.close()
     if rank == 0 and check:
