@@ -242,8 +242,12 @@ int vbnmf_engine_run(vbnmf_engine *e, double *hyper, double fudge, int32_t max_i
  *             vbnmf_engine_set_state(e, ...) ; vbnmf_engine_allreduce(e) ; vbnmf_engine_state_finish(e)
  *             vbnmf_engine_run(e, ...)           the whole loop of vb_iterate, device-driven, on every process;
  *                                                 per step the n x r piece of the all-reduce travels beside the
- *                                                 cell-side half of the sweep, every process takes the same
- *                                                 (replicated) stop decision and queues the same collectives
+ *                                                 cell-side half of the sweep and a second, small one (the
+ *                                                 sweeps' evidence partials, 8 KB) follows that sweep; every
+ *                                                 process takes the same (replicated) stop decision and queues
+ *                                                 the same collectives.  Every rank must run the same build
+ *                                                 with the same VBNMF_NO_CONTROL_FOLD setting (it decides what
+ *                                                 the second exchange carries).
  *        or   vbnmf_engine_step_local(e, ...) ; vbnmf_engine_allreduce(e) ; vbnmf_engine_step_finish(e, ...)
  *
  * librccl is opened at run time (dlopen "librccl.so.1"); without it vbnmf_comm_create fails with
