@@ -1418,15 +1418,14 @@ int queue_vb_step(const LoopGroup &G, double fudge, bool hist, int max_it)
         if (!rc) rc = launch_vb_side(e, true);
         if (rc) return rc;
         const int32_t *stop = e->stop_ptr ? e->stop_ptr : &e->ctl->stop;
-        // Where the gene-side partials are packed into the send buffer (k_pack: a gather of 100 MB of task rows at C5, 26 us
-        // with the chip to itself; k_tail_h).  Ranks that exchange through RCCL pack on the MAIN stream, between the two
-        // sweeps: the all-reduce of n * R doubles must travel WHILE the cell-side sweep runs, and a k_pack queued beside that
-        // sweep is starved by its persistent workgroups (profiles/r04_c5_step_timeline.txt: 168 us, ending after the sweep
-        // -- the collective would start when the sweep is over).  The partitions of a local group share one GPU and
-        // their exchange is a 5 us kernel: there the pack goes to the comm stream, where the other partitions' kernels fill
-        // the chip around it (-12 us per partition step on the same box).  VBNMF_PACK_ON_MAIN=1 / 0 forces either.
-        static const int pack_env = [] { const char *v = getenv("VBNMF_PACK_ON_MAIN"); return !v ? -1 : (v[0] == '1' ? 1 : 0); }();
-        const bool pack_on_main = pack_env >= 0 ? pack_env == 1 : c->kind == 0;
+        // The gene-side partials are packed into the send buffer (k_pack_tail: a gather of 100 MB of task rows at C5, 26 us
+        // with the chip to itself, + the cell side's column sums) on the MAIN stream, between the two sweeps: the all-reduce
+        // of n * R doubles must travel WHILE the cell-side sweep runs, and a pack queued beside that sweep on the comm
+        // stream is starved by its persistent workgroups (profiles/r04_c5_step_timeline.txt: 168 us, ending after the
+        // sweep -- the collective would start when the sweep is over).  VBNMF_PACK_ON_MAIN=0 puts it on the comm stream
+        // (A/B switch: round 4's first half ran it there; on the final build it is slower for a local group of eight as
+        // well, 0.373-0.376 against 0.370-0.371 ms per partition step on the same box).
+        static const bool pack_on_main = [] { const char *v = getenv("VBNMF_PACK_ON_MAIN"); return !(v && v[0] == '0'); }();
         hipStream_t ps = pack_on_main ? e->stream : e->cstream;
         if (!pack_on_main) {
             hipEvent_t evS = next_event(e);
