@@ -70,6 +70,8 @@ SIGNATURES = {
     "vbnmf_matrix_plan_ranks": (ctypes.c_int, [_VP, c_int32_p, _I32, _I32]),
     "vbnmf_plan_classes": (ctypes.c_int, [c_int32_p, _I32, _I32, c_int32_p, c_int32_p]),
     "vbnmf_padded_rank": (_I32, [_I32]),
+    "vbnmf_host_threads": (_I32, []),
+    "vbnmf_set_host_threads": (_I32, [_I32]),
     "vbnmf_matrix_get_meta": (ctypes.c_int, [_VP, c_double_p]),
     "vbnmf_matrix_shell": (ctypes.c_int, [c_double_p, _VPP]),
     "vbnmf_matrix_is_shell": (ctypes.c_int, [_VP]),

@@ -23,6 +23,7 @@ int fail(int code, const char *fmt, ...);
 void parallel_for(int64_t count, const std::function<void(int64_t begin, int64_t end, int tid)> &fn,
                   int max_threads = 0);
 int host_threads();
+void set_host_threads_override(int n);      // 0: back to the default rule (cores of the affinity mask, at most 32)
 
 // The same matrix by rows (genes), columns ascending in each row: what the gene side of the layout is cut from.
 struct RowMajor {

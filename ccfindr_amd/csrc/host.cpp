@@ -54,8 +54,13 @@ int fail(int code, const char *fmt, ...)
 const char *last_error_cstr() { return g_err.c_str(); }
 
 // ------------------------------------------------------------------ threads
+static std::atomic<int> g_host_threads_override{0};         // vbnmf_set_host_threads (0: the default rule below)
+void set_host_threads_override(int n) { g_host_threads_override.store(n > 0 ? std::min(n, 1024) : 0, std::memory_order_relaxed); }
+
 int host_threads()
 {
+    const int forced = g_host_threads_override.load(std::memory_order_relaxed);
+    if (forced > 0) return forced;
     static int n = [] {
         if (const char *s = getenv("VBNMF_HOST_THREADS")) {
             int v = atoi(s);
@@ -1308,6 +1313,13 @@ LayoutParams whole_matrix_params(const vbnmf_matrix *X, int side, int geometry_r
 extern "C" {
 
 int32_t vbnmf_padded_rank(int32_t r) { return (r < 1 || r > VBNMF_MAX_RANK) ? 0 : padded_rank(r); }
+int32_t vbnmf_host_threads(void) { return host_threads(); }
+int32_t vbnmf_set_host_threads(int32_t n)
+{
+    const int32_t before = host_threads();
+    set_host_threads_override(n);
+    return before;
+}
 
 // Rank classes of a sweep (see vbnmf_matrix_plan_ranks) WITHOUT touching a matrix: classes[0..n) = padded ranks, ascending.
 int vbnmf_plan_classes(const int32_t *ranks, int32_t count, int32_t max_classes, int32_t *classes, int32_t *n_classes)

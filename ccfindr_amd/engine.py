@@ -229,6 +229,17 @@ def sweep_workgroups(device=0):
     return v.value
 
 
+def host_threads():
+    """Host threads the library's ingestion and layout cuts use in this process (vbnmf_host_threads)."""
+    return int(N.load().vbnmf_host_threads())
+
+
+def set_host_threads(n):
+    """Lift or lower the library's host thread count for this process (0: back to the default rule -- the cores of the
+    affinity mask, at most 32); returns the count in force before (vbnmf_set_host_threads)."""
+    return int(N.load().vbnmf_set_host_threads(int(n)))
+
+
 def device_warmup(device=0):
     """First use of the device by this process, ahead of need (vbnmf_device_warmup)."""
     N.check(N.load().vbnmf_device_warmup(int(device)))

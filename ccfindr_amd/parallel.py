@@ -220,6 +220,21 @@ def vb_factorize_sharded(mat, ranks=2, nrun=1, verbose=0, initializer="random", 
                 except BaseException as exc:             # noqa: BLE001
                     errors.append(exc)
 
+            # The peers of this node wait for these cuts and their cores idle: the builder takes its share of the node's cores
+            # for the duration (the library's default stops at 32 threads per process, a cap meant for ranks that all work at
+            # once).  Layouts and cell order do not depend on the thread count.
+            from .engine import host_threads, set_host_threads
+            builders_here = max(1, len(set(b for b in builder_of.values() if b in my_node)))
+            try:
+                cores = len(os.sched_getaffinity(0))
+            except (AttributeError, OSError):
+                cores = os.cpu_count() or 1
+            want = min(128, cores // builders_here)
+            lifted = want > host_threads() and not os.environ.get("VBNMF_HOST_THREADS")
+            if lifted:
+                set_host_threads(want)
+            if detail is not None:
+                detail["cut_threads"] = host_threads()
             try:
                 X.prepare_async()                        # cell order, then the row-major copy, beside the cut of the cell side
                 for pc in pieces:
@@ -242,6 +257,9 @@ def vb_factorize_sharded(mat, ranks=2, nrun=1, verbose=0, initializer="random", 
                     fh.write(f"{type(exc).__name__}: {exc}")
                 cleanup.append(os.path.join(shm.shm_dir(), failed_name(me)))
                 raise
+            finally:
+                if lifted:
+                    set_host_threads(0)
         if sharing:
             t0 = tick()
             for pc in pieces:

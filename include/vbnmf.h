@@ -108,6 +108,14 @@ int vbnmf_matrix_plan_ranks(vbnmf_matrix *X, const int32_t *ranks, int32_t count
  * the device pads it (even up to 32, multiples of 8 up to 64, of 16 up to 128); 0 for a rank out of range. */
 int vbnmf_plan_classes(const int32_t *ranks, int32_t count, int32_t max_classes, int32_t *classes, int32_t *n_classes);
 int32_t vbnmf_padded_rank(int32_t r);
+/* Host threads of the library's ingestion and layout cuts (the reference is single-threaded: src/vbnmf_update.cpp has
+ * no host parallelism at all).  Default: the cores of the process's affinity mask, at most 32 (VBNMF_HOST_THREADS
+ * overrides) -- a cap chosen for ranks that all work at once.  vbnmf_set_host_threads(n) lifts or lowers it for THIS
+ * process until called again with 0 and returns the count in force before: the one process of a node that cuts the
+ * layouts for its waiting peers (vb_factorize_sharded) takes their cores for the duration of the cut.  Results do not
+ * depend on the count (layouts, cell order: fixed chunking; the sums of ingestion are taken once, by the holder of X). */
+int32_t vbnmf_host_threads(void);
+int32_t vbnmf_set_host_threads(int32_t n);
 void vbnmf_matrix_destroy(vbnmf_matrix *X);
 
 /* ---------------------------------------------------------------------------------

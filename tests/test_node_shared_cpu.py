@@ -190,3 +190,33 @@ def test_share_and_attach_a_layout_without_copies(wide, tmp_path):
         assert open(path2, "rb").read() == bytes(want)
         os.unlink(path2)
     plain.close(); sharer.close(); shell.close()
+
+
+def test_layouts_do_not_depend_on_the_host_thread_count():
+    """vbnmf_set_host_threads lifts the library's thread count for one process (the builder of a node's layouts takes its
+    waiting peers' cores): cell order, row-major copy and both tiled layouts come out the same bytes whatever the count."""
+    import ccfindr_amd as C
+    from ccfindr_amd.engine import host_threads, set_host_threads
+    X = _matrix(seed=9)
+    default = host_threads()
+    assert default >= 1
+    blobs = {}
+    try:
+        for nt in (1, 3, 7, 0):
+            before = set_host_threads(nt)
+            assert before >= 1 and host_threads() == (nt if nt else default)
+            os.environ["VBNMF_CELL_ORDER"] = "1"                     # the ordering too (off by default at this size)
+            M = C.CountMatrix(X)
+            out = []
+            for side in (1, 0):
+                nb = M.layout_blob_size(side, 10, 256)
+                blob = bytearray(nb)
+                M.export_layout(side, 10, 256, blob)
+                out.append(bytes(blob))
+            blobs[nt] = out
+            M.close()
+    finally:
+        os.environ.pop("VBNMF_CELL_ORDER", None)
+        set_host_threads(0)
+    for nt in (3, 7, 0):
+        assert blobs[nt][0] == blobs[1][0] and blobs[nt][1] == blobs[1][1], nt
