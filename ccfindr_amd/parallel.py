@@ -229,6 +229,7 @@ def vb_factorize_sharded(mat, ranks=2, nrun=1, verbose=0, initializer="random", 
                 cores = len(os.sched_getaffinity(0))
             except (AttributeError, OSError):
                 cores = os.cpu_count() or 1
+            cores = int(os.environ.get("VBNMF_TEST_NODE_CORES") or 0) or cores        # test hook: pretend the node has this many
             want = min(128, cores // builders_here)
             lifted = want > host_threads() and not os.environ.get("VBNMF_HOST_THREADS")
             if lifted:

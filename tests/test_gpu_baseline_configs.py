@@ -168,6 +168,7 @@ def _c4_worker(rank, world, port, path, q):
             z = np.load(path, mmap_mode="r")
             X = sp.csc_matrix((np.asarray(z["data"]), np.asarray(z["indices"]), np.asarray(z["indptr"])), shape=tuple(z["shape"]))
         tm = {}
+        os.environ["VBNMF_TEST_NODE_CORES"] = "40"          # the builder of the node's layouts takes its waiting peer's cores
         res = parallel.vb_factorize_sharded(X, ranks=[4, 10, 17], nrun=1, Itmax=12, seed=11, device=0, timings=tm)
         q.put((rank, res.ranks, res.measure, res.nsteps, [np.asarray(b).copy() for b in res.basis],
                [np.asarray(b).copy() for b in res.dcoeff], tm))
@@ -199,6 +200,7 @@ def test_config4_sharded_sweep_two_processes_on_the_headline_matrix(c3, tmp_path
         assert p.exitcode == 0
     assert all(np.isfinite(v) for v in single.measure["lml"])
     assert [o[-1]["is_shell"] for o in outs] == [False, True] and all(o[-1]["node_processes"] == 2 for o in outs)
+    assert outs[0][-1]["layout_detail"].get("cut_threads") == 40      # (and the results below are still the single process's, bit for bit)
     for _, ranks, measure, nsteps, basis, dcoeff, _tm in outs:
         assert ranks == single.ranks and nsteps == single.nsteps and measure == single.measure
         for a, b in zip(basis, single.basis):
