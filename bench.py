@@ -300,6 +300,14 @@ def measure_sweep_traffic(timeout_s=300.0):
     import tempfile
     if os.environ.get("BENCH_NO_TRAFFIC"):
         return None, "skipped (BENCH_NO_TRAFFIC)"
+    # Already under a profiler (rocprofv3 -- python3 bench.py ...): a nested launcher would inherit the outer profiler's
+    # preloaded tool library, which touches the GPU before the inner launcher execs its target -- the exec this pool forbids --
+    # and the extra passes would skew the traced run (profiles/ubench/r04/stage_ids_ab.sh ran exactly that).
+    prof = ("ROCPROF", "ROCP_", "ROCPROFILER", "ROCTRACER")
+    marks = [k for k in os.environ if k.startswith(prof)]
+    preload = os.environ.get("LD_PRELOAD", "")
+    if marks or "rocprof" in preload or "roctx" in preload:
+        return None, "already under a profiler (%s)" % ", ".join(marks[:3] or ["LD_PRELOAD"])
     tool = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if not tool:
         return None, "rocprofv3 not found"
@@ -307,7 +315,8 @@ def measure_sweep_traffic(timeout_s=300.0):
     t_all = time.perf_counter()
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         out = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
-        env = dict(os.environ, BENCH_NO_SWEEP="1", BENCH_NO_TRAFFIC="1", TMPDIR="/tmp")
+        env = {k: v for k, v in os.environ.items() if not k.startswith(prof) and k != "LD_PRELOAD"}
+        env.update(BENCH_NO_SWEEP="1", BENCH_NO_TRAFFIC="1", TMPDIR="/tmp")
         cmd = [tool, "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "pmc", "--", sys.executable,
                os.path.abspath(__file__), "--steps", "24", "--warmup", "2", "--no-cpu", "--no-ml"]
         try:

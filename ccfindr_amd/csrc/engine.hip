@@ -23,6 +23,7 @@
 #include <cstring>
 #include <memory>
 #include <new>
+#include <queue>
 #include <string>
 #include <thread>
 
@@ -230,6 +231,12 @@ struct vbnmf_engine {
     double *lh = nullptr, *llh = nullptr, *eh = nullptr, *dh = nullptr;
     double *epart = nullptr;          // [2 * n_wg] evidence partials: gene side, then cell side
     double *bpW = nullptr, *bpH = nullptr;   // [ub][R+2] block partials of the two updates (allocated for kUpdateBlocks rows)
+    // Both posterior updates in one launch (kernels.h: k_update2; unpartitioned engines): the gene side of the sweep leaves
+    // per-slice column sums of sw (csl) and their per-workgroup sums (csum); both tables of block partials alternate.
+    double *csl = nullptr, *csum = nullptr;  // [A.n_slices][R], [n_wg][R]
+    bool pair = false;
+    uint4 *upd_tab = nullptr;                // k_update2's work table, one row per block (build_update_table)
+    int32_t upd_stride4 = 0, upd_V = 0, upd_ids_off = 0;
     int ub = kUpdateBlocks;           // blocks of the update kernels (one per CU; VBNMF_UPDATE_BLOCKS for experiments)
     double *red = nullptr;            // [n*R | R+4]  (partitioned engines only use the first part)
     int64_t red_count = 0;
@@ -392,6 +399,7 @@ SweepSide sweep_side_args(const vbnmf_engine *e, const DeviceSide &S, bool gene_
     P.llF = gene_side ? e->llw : e->llh;
     P.G = gene_side ? e->lh : e->lw;
     P.part = S.part; P.epart = epart;
+    P.csl = gene_side ? e->csl : nullptr; P.csum = gene_side ? e->csum : nullptr;
     P.n_minor = (int32_t)S.n_minor; P.block_start = S.block_start;
     P.row_slots = S.row_slots;
     {
@@ -459,7 +467,11 @@ int launch_sweep_r(vbnmf_engine *e, const SweepSide &a, const SweepSide &b)
     X(2) X(4) X(6) X(8) X(10) X(12) X(14) X(16) X(18) X(20) X(22) X(24) X(26) X(28) X(30) X(32) \
     X(40) X(48) X(56) X(64)
 // every padded rank: up to 32 by 2 (one lane per task), 40..64 by 8 (two lanes), 80..128 by 16 (four lanes)
+#ifdef VBNMF_DEV_FEW_RANKS              /* development builds only: a few ranks, for a compile check in a minute */
+#define VBNMF_FOR_EACH_R(X) X(4) X(10) X(20) X(48) X(80)
+#else
 #define VBNMF_FOR_EACH_R(X) VBNMF_FOR_EACH_R_UP_TO_64(X) X(80) X(96) X(112) X(128)
+#endif
 
 int launch_sweep(vbnmf_engine *e)
 {
@@ -506,6 +518,118 @@ int launch_update(vbnmf_engine *e, bool gene_side, double a, double b, double fu
     const int stage_ids = stage_allowed && !dense && S.n_tasks >= (int64_t)256 * grid ? 1 : 0;
     switch (e->R) {
 #define X(RR) case RR: hipLaunchKernelGGL((k_update<RR>), dim3(grid), dim3(kUpdateThreads), 0, e->stream, acc, inv_ptr, inv_task, nmaj, e->r, other, other_bp, other_nb, a, b, lga, fudge, l, ll, ev, d, bp, ctl, side, fold, stage_ids); break;
+        VBNMF_FOR_EACH_R(X)
+#undef X
+        default: return fail(VBNMF_ERR_BAD_ARG, "unsupported padded rank %d", e->R);
+    }
+    HIPCHECK(hipGetLastError());
+    return VBNMF_OK;
+}
+
+// The work table of k_update2 (kernels.h): per block of the update, the visits of every thread row -- the block's genes
+// and cells dealt to the rows longest-processing-time first -- and the task ids of those majors.  The gather is bound by the
+// task rows it moves (a round of 16 scattered loads takes about as long as the whole posterior arithmetic behind it,
+// in-kernel stamps), so a major costs its task count plus a few loads' worth of fixed work.  Every block's row has the same
+// shape (stride, visits per thread row, offset of the ids), so the kernel loads it without knowing anything first.
+// Returns false when a block's row does not fit the kernel's LDS copy: the engine then keeps the two-launch form.
+bool build_update_table(const Layout &LA, const Layout &LB, int ub, int R, std::vector<uint32_t> &tab, int32_t &stride4, int32_t &V,
+                        int32_t &ids_off)
+{
+    const int RB = kUpdateThreads / R;
+    const int64_t nm[2] = {LA.n_major, LB.n_major};
+    const Layout *Ls[2] = {&LA, &LB};
+    const int64_t per[2] = {(nm[0] + ub - 1) / ub, (nm[1] + ub - 1) / ub};
+    struct Item { int32_t cost; uint32_t code; int32_t cnt; };
+    struct Plan { std::vector<std::vector<Item>> rows; int64_t ids = 0; int vmax = 0; };
+    std::vector<Plan> plans(ub);
+    parallel_for(ub, [&](int64_t b0, int64_t b1, int) {
+        std::vector<Item> items;
+        for (int64_t b = b0; b < b1; b++) {
+            Plan &P = plans[b];
+            items.clear();
+            for (int sd = 0; sd < 2; sd++) {
+                const int64_t m0 = std::min(nm[sd], b * per[sd]), m1 = std::min(nm[sd], m0 + per[sd]);
+                for (int64_t M = m0; M < m1; M++) {
+                    const int32_t cnt = Ls[sd]->inv_ptr[M + 1] - Ls[sd]->inv_ptr[M];
+                    items.push_back({cnt + 4, ((uint32_t)sd << 31) | (uint32_t)(M - m0), cnt});
+                    P.ids += cnt;
+                }
+            }
+            std::sort(items.begin(), items.end(), [](const Item &x, const Item &y) { return x.cost != y.cost ? x.cost > y.cost : x.code < y.code; });
+            P.rows.assign(RB, {});
+            // (load, row): the least loaded row takes the next item; ties go to the lowest row -- the plan is a function of the layouts alone
+            std::priority_queue<std::pair<int64_t, int>, std::vector<std::pair<int64_t, int>>, std::greater<std::pair<int64_t, int>>> pq;
+            for (int q = 0; q < RB; q++) pq.push({0, q});
+            for (const Item &it : items) {
+                auto top = pq.top(); pq.pop();
+                P.rows[top.second].push_back(it);
+                pq.push({top.first + it.cost, top.second});
+            }
+            for (int q = 0; q < RB; q++) {                  // a row visits its genes first, then its cells (k_update2's two loops)
+                std::stable_sort(P.rows[q].begin(), P.rows[q].end(), [](const Item &x, const Item &y) { return (x.code >> 31) < (y.code >> 31); });
+                P.vmax = std::max(P.vmax, (int)P.rows[q].size());
+            }
+        }
+    });
+    int64_t max_ids = 0;
+    V = 1;
+    for (const Plan &P : plans) { max_ids = std::max(max_ids, P.ids); V = std::max(V, (int32_t)P.vmax); }
+    const int64_t vis_words = ((int64_t)RB * V * 3 + 3) & ~(int64_t)3;
+    const int64_t stride = (vis_words + max_ids + 3) & ~(int64_t)3;
+    if (stride > kUpdTabWords) return false;
+    ids_off = (int32_t)vis_words;
+    stride4 = (int32_t)(stride / 4);
+    tab.assign((size_t)ub * stride, 0u);
+    parallel_for(ub, [&](int64_t b0, int64_t b1, int) {
+        std::vector<int32_t> first[2];                      // first id slot of each of the block's majors, by side
+        for (int64_t b = b0; b < b1; b++) {
+            uint32_t *row = tab.data() + (size_t)b * stride;
+            int32_t q = 0;
+            for (int sd = 0; sd < 2; sd++) {
+                const int64_t m0 = std::min(nm[sd], b * per[sd]), m1 = std::min(nm[sd], m0 + per[sd]);
+                first[sd].assign((size_t)(m1 - m0) + 1, 0);
+                for (int64_t M = m0; M < m1; M++) {
+                    first[sd][M - m0] = q;
+                    for (int32_t u = Ls[sd]->inv_ptr[M]; u < Ls[sd]->inv_ptr[M + 1]; u++) row[ids_off + q++] = Ls[sd]->inv_task[u];
+                }
+                first[sd][m1 - m0] = q;
+            }
+            const Plan &P = plans[b];
+            for (int rr = 0; rr < RB; rr++) {
+                uint32_t *vis = row + (size_t)rr * V * 3;
+                int v = 0;
+                for (const Item &it : P.rows[rr]) {
+                    const int sd = (int)(it.code >> 31);
+                    const uint32_t loc = it.code & 0x7FFFFFFFu;
+                    vis[3 * v] = it.code; vis[3 * v + 1] = (uint32_t)first[sd][loc]; vis[3 * v + 2] = (uint32_t)(first[sd][loc] + it.cnt);
+                    v++;
+                }
+                for (; v < V; v++) { vis[3 * v] = 0xFFFFFFFFu; vis[3 * v + 1] = 0; vis[3 * v + 2] = 0; }
+            }
+        }
+    });
+    return true;
+}
+
+// Both posterior updates in one launch (kernels.h: k_update2).  Both tables of block partials alternate: the launch reads
+// the previous ones and writes the others; e->bpW / e->bpH always name the latest.
+int launch_update2(vbnmf_engine *e, double aw, double bw, double ah, double bh, double fudge, const LoopCtl *ctl = nullptr,
+                   const ControlFold *foldp = nullptr)
+{
+    ControlFold fold{};
+    if (foldp) fold = *foldp;
+    const unsigned grid = (unsigned)e->ub;
+    UpdSide W{}, H{};
+    W.part = e->A.part; W.nmaj = e->n;
+    W.l = e->lw; W.ll = e->llw; W.e = e->ew; W.d = e->dw;
+    H.part = e->B.part; H.nmaj = e->m;
+    H.l = e->lh; H.ll = e->llh; H.e = e->eh; H.d = e->dh;
+    UpdTable T{e->upd_tab, e->upd_stride4, e->upd_V, e->upd_ids_off};
+    W.bp_prev = e->bpW; H.bp_prev = e->bpH;
+    std::swap(e->bpW, e->bpW_alt); std::swap(e->bpH, e->bpH_alt);
+    W.bp = e->bpW; H.bp = e->bpH;
+    switch (e->R) {
+#define X(RR) case RR: hipLaunchKernelGGL((k_update2<RR>), dim3(grid), dim3(kUpdateThreads), 0, e->stream, W, H, T, e->r, e->ub, (const double *)e->csum, e->n_wg, aw, bw, ah, bh, fudge, ctl, fold); break;
         VBNMF_FOR_EACH_R(X)
 #undef X
         default: return fail(VBNMF_ERR_BAD_ARG, "unsupported padded rank %d", e->R);
@@ -842,7 +966,7 @@ void vbnmf_engine_destroy(vbnmf_engine *e)
     dev_free(e->lw); dev_free(e->llw); dev_free(e->ew); dev_free(e->dw);
     dev_free(e->lh); dev_free(e->llh); dev_free(e->eh); dev_free(e->dh);
     if (!e->epart_in_red) dev_free(e->epart);
-    dev_free(e->bpW); dev_free(e->bpH);
+    dev_free(e->bpW); dev_free(e->bpH); dev_free(e->csl); dev_free(e->csum); dev_free(e->upd_tab);
     dev_free(e->d_perm); dev_free(e->d_ids[0]); dev_free(e->d_ids[1]); dev_free(e->d_table); dev_free(e->svd_ws); dev_free(e->svd_status);
     dev_free(e->red); dev_free(e->red_g); dev_free(e->d_out);
     for (hipEvent_t ev : e->ev_ring) (void)hipEventDestroy(ev);
@@ -901,6 +1025,9 @@ int vbnmf_engine_create_geom(const vbnmf_matrix *X, int64_t cb, int64_t ce, int6
     try {
         std::vector<int32_t> part_order;                         // a partition orders its own cells (both sides alike)
         if (!(cb == 0 && ce == X->M.m)) part_order = compute_cell_order(X->M, cb, ce);
+        std::shared_ptr<const Layout> shared2[2];
+        Layout own2[2];
+        const Layout *Ls[2] = {nullptr, nullptr};
         for (int side = 0; side < 2 && !rc; side++) {
             int64_t nmaj = side == 0 ? e->n : e->m, nmin = side == 0 ? e->m : e->n;
             // The geometry is that of the matrix's rank CLASS (vbnmf_matrix_plan_ranks; without a plan the class is this
@@ -908,8 +1035,8 @@ int vbnmf_engine_create_geom(const vbnmf_matrix *X, int64_t cb, int64_t ce, int6
             const int Rc = geometry_rank ? padded_rank(geometry_rank) : std::max(e->R, plan_class(X, e->R));
             const int64_t nnz_part = (cb == 0 && ce == X->M.m) ? X->M.nnz : X->M.colptr[ce] - X->M.colptr[cb];
             LayoutParams lp = default_layout_params(nmaj, nmin, Rc, e->n_wg, nnz_part);
-            std::shared_ptr<const Layout> shared;
-            Layout own;
+            std::shared_ptr<const Layout> &shared = shared2[side];
+            Layout &own = own2[side];
             const Layout *L = &own;
             if (cb == 0 && ce == X->M.m) {                   // whole matrix: the layout may already exist (another rank, a restart)
                 shared = shared_layout(X, side, lp, rc);
@@ -920,6 +1047,30 @@ int vbnmf_engine_create_geom(const vbnmf_matrix *X, int64_t cb, int64_t ce, int6
             if (!rc) rc = upload_side(*L, e->R, device, shared ? X : nullptr, side == 0 ? e->A : e->B);
             if (!rc && side == 0) { e->nnz = L->nnz; e->cell_perm = L->cell_perm; }
             if (!rc && side == 1 && L->cell_perm != e->cell_perm) rc = fail(VBNMF_ERR_STATE, "the two sides' layouts disagree on the order of the cells");
+            Ls[side] = L;
+        }
+        if (!rc) {
+            // One launch for both posterior updates (k_update2): unpartitioned engines whose blocks' work fits the kernel's
+            // table; VBNMF_NO_UPDATE_PAIR=1 keeps the two launches (A/B switch, and the form the pair is held to in
+            // tests/test_gpu_update_pair.py).
+            // Where it pays (round 5, same-box A/Bs in profiles/r05_pair_ab*.txt, r05_small_pair_ab.txt): the launch it saves is
+            // worth ~3 us of a step whatever the size, the column sums it needs cost the gene side of the sweep ~60 + 4 R
+            // instructions per SLICE.  5 000 x 20 000 at rank 8: 64.0 -> 60.1 us per step (+6 %); C2 (2 000 x 10 000 dense,
+            // rank 5) +1.9 %; C1 and the PBMC-sized sample +-0; the headline (4.9e7 entries, rank 10) -0.3 %, rank 20 -1.2 %.
+            // So: on up to 2.5e8 entries x padded rank, off beyond.  VBNMF_UPDATE_PAIR=1 / VBNMF_NO_UPDATE_PAIR=1 force it.
+            const char *np = getenv("VBNMF_NO_UPDATE_PAIR"), *fp = getenv("VBNMF_UPDATE_PAIR");
+            const bool forced = fp && fp[0] == '1';
+            const bool pays = (double)Ls[0]->nnz * (double)e->R <= 2.5e8;
+            e->pair = !e->partitioned && !(np && np[0] == '1') && (forced || pays) && Ls[0]->n_wg == Ls[1]->n_wg;
+            if (e->pair) {
+                std::vector<uint32_t> tab;
+                e->pair = build_update_table(*Ls[0], *Ls[1], e->ub, e->R, tab, e->upd_stride4, e->upd_V, e->upd_ids_off);
+                if (e->pair) {
+                    uint32_t *d = nullptr;
+                    rc = dev_upload(&d, tab);
+                    e->upd_tab = reinterpret_cast<uint4 *>(d);
+                }
+            }
         }
     } catch (const std::bad_alloc &) {
         rc = fail(VBNMF_ERR_OOM, "out of host memory building the tiled layout");
@@ -944,11 +1095,16 @@ int vbnmf_engine_create_geom(const vbnmf_matrix *X, int64_t cb, int64_t ce, int6
         const char *nf = getenv("VBNMF_NO_CONTROL_FOLD");
         // (partitioned engines: the evidence partials of the two sweeps must fit the fixed slots of the second all-reduce)
         e->fold = !(nf && nf[0] == '1') && (!e->partitioned || 2 * (int64_t)e->n_wg <= kEvSlots);
-        if (e->fold) {
-            if ((rc = dev_alloc(&e->ctl2, 2)) || (rc = dev_alloc(&e->bpW_alt, (size_t)kUpdateBlocks * (e->R + 2))) ||
+        if (e->fold && (rc = dev_alloc(&e->ctl2, 2))) return bail(rc);
+        if (e->fold || e->pair) {
+            if ((rc = dev_alloc(&e->bpW_alt, (size_t)kUpdateBlocks * (e->R + 2))) ||
                 (rc = dev_alloc(&e->bpH_alt, (size_t)kUpdateBlocks * (e->R + 2)))) return bail(rc);
             if (hipMemset(e->bpW_alt, 0, (size_t)kUpdateBlocks * (e->R + 2) * sizeof(double)) != hipSuccess ||
                 hipMemset(e->bpH_alt, 0, (size_t)kUpdateBlocks * (e->R + 2) * sizeof(double)) != hipSuccess) return bail(fail(VBNMF_ERR_HIP, "hipMemset failed"));
+        }
+        if (e->pair) {
+            if ((rc = dev_alloc(&e->csl, (size_t)std::max<int64_t>(e->A.n_slices, 1) * e->R)) || (rc = dev_alloc(&e->csum, (size_t)e->n_wg * e->R))) return bail(rc);
+            if (hipMemset(e->csum, 0, (size_t)e->n_wg * e->R * sizeof(double)) != hipSuccess) return bail(fail(VBNMF_ERR_HIP, "hipMemset failed"));
         }
     }
 
@@ -1125,6 +1281,13 @@ int vbnmf_engine_set_state(vbnmf_engine *e, const double *lw, const double *lh, 
 {
     if (!e || !lw || !lh || !eh) return fail(VBNMF_ERR_BAD_ARG, "NULL argument");
     if (int rc = use_device(e)) return rc;
+    if (e->prime_pending) {
+        // A partitioned engine's previous set_state returned with its copies out of the pinned staging buffer still queued
+        // (state_finish waits for them): rewriting that buffer -- or handing it to the pool when it grows -- under in-flight
+        // DMA would load a corrupted state without any error.  Wait for the stream first (bounded: a state exchange whose peer
+        // never joined sits on it).
+        if (int rc = bounded_stream_sync(e, e->stream, "the previous set_state of this engine")) return rc;
+    }
     e->has_state = false; e->stats_ready = false; e->step_pending = false; e->prime_pending = false;
     e->ml_ready = false;
     {
@@ -1184,8 +1347,12 @@ int vbnmf_engine_step_local(vbnmf_engine *e, double aw, double bw, double ah, do
     if (int rc = use_device(e)) return rc;                                   // (first: an engine that timed out says so, whatever its state)
     if (!e->has_state || !e->stats_ready) return fail(VBNMF_ERR_STATE, "step before set_state (or before state_finish on a partitioned engine)");
     if (e->step_pending) return fail(VBNMF_ERR_STATE, "step_local called twice without step_finish");
-    if (int rc = launch_update(e, true, aw, bw, fudge)) return rc;
-    if (int rc = launch_update(e, false, ah, bh, fudge)) return rc;
+    if (e->pair) {
+        if (int rc = launch_update2(e, aw, bw, ah, bh, fudge)) return rc;
+    } else {
+        if (int rc = launch_update(e, true, aw, bw, fudge)) return rc;
+        if (int rc = launch_update(e, false, ah, bh, fudge)) return rc;
+    }
     if (int rc = launch_sweep(e)) return rc;
     if (e->partitioned) { if (int rc = launch_pack(e)) return rc; }
     e->step_pending = true;
@@ -1350,15 +1517,22 @@ int queue_vb_step(const LoopGroup &G, double fudge, bool hist, int max_it)
         const int t = ++e->fold_step;                               // 1-based step of this run
         ControlFold f{};
         f.prev = e->ctl2 + ((t - 1) & 1); f.next = e->ctl2 + (t & 1);
-        f.bpW_prev = e->bpW;
-        std::swap(e->bpW, e->bpW_alt);                              // this step's gene-side partials go to the other table
         f.epart = e->epart; f.nepart = 2 * (int64_t)e->n_wg;
         f.lgx = e->lgx; f.n = (double)e->n; f.m_global = (double)e->m_global;
         f.history = hist ? e->h_hist_dev : nullptr; f.out_host = e->h_out_dev;
         f.do_control = t > 1 ? 1 : 0;
-        int rc = launch_update(e, true, 0, 0, fudge, nullptr, &f);
-        e->stop_ptr = &f.next->stop;
-        if (!rc) rc = launch_update(e, false, 0, 0, fudge, f.next);
+        int rc;
+        if (e->pair) {
+            // k_update2(W and H, with the control step of the previous sweep folded in)  k_sweep : two launches per step
+            rc = launch_update2(e, 0, 0, 0, 0, fudge, nullptr, &f);
+            e->stop_ptr = &f.next->stop;
+        } else {
+            f.bpW_prev = e->bpW;
+            std::swap(e->bpW, e->bpW_alt);                          // this step's gene-side partials go to the other table
+            rc = launch_update(e, true, 0, 0, fudge, nullptr, &f);
+            e->stop_ptr = &f.next->stop;
+            if (!rc) rc = launch_update(e, false, 0, 0, fudge, f.next);
+        }
         if (!rc) rc = launch_sweep(e);
         if (!rc && t == max_it) {
             ControlFold g = f;
@@ -1371,8 +1545,12 @@ int queue_vb_step(const LoopGroup &G, double fudge, bool hist, int max_it)
     }
     if (!G.comm) {
         vbnmf_engine *e = G.e[0];
-        int rc = launch_update(e, true, 0, 0, fudge, e->ctl);
-        if (!rc) rc = launch_update(e, false, 0, 0, fudge, e->ctl);
+        int rc;
+        if (e->pair) rc = launch_update2(e, 0, 0, 0, 0, fudge, e->ctl);
+        else {
+            rc = launch_update(e, true, 0, 0, fudge, e->ctl);
+            if (!rc) rc = launch_update(e, false, 0, 0, fudge, e->ctl);
+        }
         if (!rc) rc = launch_sweep(e);
         if (!rc) rc = launch_control(e, hist ? e->h_hist_dev : nullptr, false);
         return rc;
@@ -2507,9 +2685,14 @@ int stateless_engine(int kind, int64_t n, int64_t m, int64_t nnz, uint64_t hash,
         if (colptr) C.colptr.assign(colptr, colptr + m + 1);
         if (dense) for (size_t o = 0; o < total; o += stride) C.sample.push_back(dense[o]);
     }
-    if (!C.e || C.r != r) {
+    // The stateless entries take no device argument (the reference's signature has none): VBNMF_DEVICE names it, read at
+    // every call, so the slaves of Rmpi::mpi.applyLB (reference R/bayesian.R:262-263) that call the plain shim can each be
+    // given their own GPU; default device 0.
+    int device = 0;
+    if (const char *dv = getenv("VBNMF_DEVICE")) device = atoi(dv);
+    if (!C.e || C.r != r || C.e->device != device) {
         vbnmf_engine_destroy(C.e); C.e = nullptr;
-        if (int rc = vbnmf_engine_create(C.X, r, 0, &C.e)) { C.e = nullptr; return rc; }
+        if (int rc = vbnmf_engine_create(C.X, r, device, &C.e)) { C.e = nullptr; return rc; }
         C.r = r;
     }
     *out = C.e;

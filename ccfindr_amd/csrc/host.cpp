@@ -1537,6 +1537,35 @@ int load_blob(const vbnmf_matrix *X, const void *buf, int64_t bytes, std::shared
                         L->n_major == (L->side == 0 ? X->M.n : X->M.m) && L->n_minor == (L->side == 0 ? X->M.m : X->M.n) &&
                         L->wide == !X->M.counts_int;
         if (!ok) return fail(VBNMF_ERR_BAD_ARG, "layout blob: header and arrays disagree");
+        // ... and the CONTENTS of the small arrays are what the kernels index device memory by: a blob from another build with
+        // the same version word, or a half-overwritten mapping, must be an error here, not an out-of-bounds access on the GPU.
+        // (The entry stream itself addresses LDS rows only: its offsets are masked to the staged block.)
+        {
+            const char *bad = nullptr;
+            const int64_t nsl = L->n_slices, nseg = L->n_segs;
+            if (L->n_blocks < 1 || L->n_wg < 1 || L->row_slots < 1 || !(L->row_slots & 1) || L->max_len < 4 || L->block_width < 1) bad = "geometry";
+            for (int64_t q = 0; !bad && q < nsl; q++) {
+                const int64_t w = L->slice_width[q], o = L->slice_off[q];
+                if (w < 4 || (w & 3) || w > L->max_len + 3 || o < 0 || (o & 255) || o + w * kLanes > L->n_slots) bad = "slice_off / slice_width";
+                else if ((L->slice_fast[q] & 0xFFFF) > w || ((L->slice_fast[q] >> 16) & 0xFFFF) > w) bad = "slice_fast";
+            }
+            for (size_t q = 0; !bad && q < L->task_major.size(); q++)
+                if (L->task_major[q] != kIdleLane && (int64_t)L->task_major[q] >= L->n_major) bad = "task_major";
+            if (!bad && (L->block_start[0] != 0 || L->block_start[L->n_blocks] != L->n_minor)) bad = "block_start";
+            for (int q = 0; !bad && q < L->n_blocks; q++) {
+                const int64_t w = L->block_start[q + 1] - L->block_start[q];
+                if (w < 1 || w > L->block_width) bad = "block_start";
+            }
+            for (int64_t q = 0; !bad && q < nseg; q++) if (L->seg_block[q] < 0 || L->seg_block[q] >= L->n_blocks) bad = "seg_block";
+            if (!bad && (L->seg_ptr[0] != 0 || L->seg_ptr[nseg] != nsl)) bad = "seg_ptr";
+            for (int64_t q = 0; !bad && q < nseg; q++) if (L->seg_ptr[q + 1] < L->seg_ptr[q]) bad = "seg_ptr";
+            if (!bad && (L->wg_seg0[0] != 0 || L->wg_seg0[L->n_wg] != nseg)) bad = "wg_seg0";
+            for (int q = 0; !bad && q < L->n_wg; q++) if (L->wg_seg0[q + 1] < L->wg_seg0[q]) bad = "wg_seg0";
+            if (!bad && (L->inv_ptr[0] != 0 || L->inv_ptr[L->n_major] != L->n_tasks)) bad = "inv_ptr";
+            for (int64_t q = 0; !bad && q < L->n_major; q++) if (L->inv_ptr[q + 1] < L->inv_ptr[q]) bad = "inv_ptr";
+            for (int64_t q = 0; !bad && q < L->n_tasks; q++) if ((int64_t)L->inv_task[q] >= nsl * kLanes) bad = "inv_task";
+            if (bad) return fail(VBNMF_ERR_BAD_ARG, "layout blob: the %s array is inconsistent (another build, or a damaged file?)", bad);
+        }
         cache_layout(X, L->side, lp, L);
     } catch (const std::bad_alloc &) {
         return fail(VBNMF_ERR_OOM, "out of host memory importing the layout");

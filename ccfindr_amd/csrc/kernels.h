@@ -54,6 +54,9 @@ struct SweepSide {
     const double *G;               // [n_minor][R]  factor gathered through LDS
     double *part;                  // [n_slices*64][R] partial statistics per task
     double *epart;                 // [n_wg] evidence partials, one per workgroup
+    double *csl;                   // [n_slices][RT] per-slice column sums of F .* acc (gene side of the VB sweep; null: not formed) ...
+    double *csum;                  // ... and [n_wg][RT] their per-workgroup sums, in list order: sum_i sw_ik without the W update
+                                   // having run (k_update2: both posterior updates in one launch)
     int32_t n_minor;
     int32_t row_slots;             // LDS row stride of the staged factor block in 16-byte slots (odd; >= R / 2: the stride of the
                                    // layout's rank class, which may be wider than this rank's own rows -- common.h, rank classes)
@@ -92,6 +95,33 @@ __device__ __forceinline__ void pin(Group4 &g)
 __device__ __forceinline__ void pin_offsets(Group4 &g)
 {
     asm volatile("" : "+v"(g.o0), "+v"(g.o1), "+v"(g.o2), "+v"(g.o3));
+}
+// The entry stream is read exactly once per sweep (400 MB at the headline size, two sides): loaded with the non-temporal
+// policy so that it does not push what IS re-read -- the factor rows, the per-task partial rows the update kernels gather
+// back, the state -- out of the 4 MB L2s and the 256 MB Infinity Cache (MI355X_MICROARCH.md: a table stays resident only
+// while everything moved between two uses of a line fits in about 256 MiB).  VBNMF_STREAM_NT=0 builds the plain loads (A/B).
+#ifndef VBNMF_STREAM_NT
+#define VBNMF_STREAM_NT 1
+#endif
+__device__ __forceinline__ uint4 ld_stream(const uint4 *p)
+{
+#if VBNMF_STREAM_NT
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ double2 ld_stream(const double2 *p)
+{
+#if VBNMF_STREAM_NT
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    const f64x2 v = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(p));
+    return make_double2(v.x, v.y);
+#else
+    return *p;
+#endif
 }
 // LDS image of the sweep: [0, kLdsTabBytes) the ln table, then kLdsEvSlots per-slice evidence
 // partials, the slice ticket counter, and from kLdsRowBase on the staged factor block.
@@ -213,6 +243,92 @@ __device__ __forceinline__ void renorm_product(SweepRegs<R> &S)
     S.pexp += k;
 }
 
+// Column sums over the 64 lanes of a wave of N values per lane, by recursive halving: at every level the lanes pair up, the
+// pair splits the columns -- one lane keeps the lower half, its partner the upper half, each adding the other's copy -- so
+// about N + log2(64) exchanges instead of 6 N; once one value per lane is left the remaining levels are plain pair sums
+// (one lane of the pair keeps the result).  Levels (bit of the lane number that tells the two halves apart : pairing):
+//   32 : lane ^ 32   v_permlane32_swap (gfx950: swaps the upper 32 lanes of one register with the lower 32 of another, so
+//   16 : lane ^ 16   v_permlane16_swap  `lo' = (lo | hi swapped); w = lo' + hi'` needs no select: 3 instructions per column)
+//    8 : lane ^ 8    DPP row_ror:8
+//    4 : 7 - lane within its 8 lanes   DPP row_half_mirror (any pairing of a low-quad lane with a high-quad lane will do;
+//        lane ^ 4 through ds_bpermute when LOW > 1: the pairing must then keep the lane's share of the task's columns)
+//    2 : lane ^ 2    DPP quad_perm [2,3,0,1]
+//    1 : lane ^ 1    DPP quad_perm [1,0,3,2]
+// Levels below LOW are not crossed (ranks above 32: the LOW = SP neighbouring lanes hold different columns of one task).
+// On return the lane holds `onv` (0, 1 or 2) finished column sums o0, o1 of columns obase, obase + 1.  Which lane ends
+// with which column depends on the lane number alone, and the tree is fixed: a slice's sums depend on nothing but its
+// tasks -- bit-reproducible.
+// XOR4: level 4 must pair lane ^ 4 (ranks above 32: the mirror pairing joins lanes that hold different columns of a task)
+template <int MASK, bool XOR4 = false>
+__device__ __forceinline__ double lane_pair_value(double v)
+{
+    static_assert(MASK == 8 || MASK == 4 || MASK == 2 || MASK == 1, "DPP levels");
+    if constexpr (MASK == 4 && XOR4) return __shfl_xor(v, 4, 64);
+    constexpr int ctrl = MASK == 8 ? 0x128 : MASK == 4 ? 0x141 : MASK == 2 ? 0x4E : 0xB1;
+    return __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(v), ctrl, 0xF, 0xF, false),
+                            __builtin_amdgcn_mov_dpp(__double2loint(v), ctrl, 0xF, 0xF, false));
+}
+// wave sum without LDS round trips: DPP inside the rows of 16 lanes (quads, half rows, rows), then gfx950's permlane swaps
+// across the rows.  Valid in every lane; a fixed tree.
+__device__ __forceinline__ double wave_sum_dpp(double v)
+{
+    v += lane_pair_value<1>(v);
+    v += lane_pair_value<2>(v);
+    v += lane_pair_value<4>(v);
+    v += lane_pair_value<8>(v);
+    {   // rows 0+1, 2+3: v_permlane16_swap of the value with a copy of itself leaves (own row, partner row) in the two registers
+        const int lo = __double2loint(v), hi = __double2hiint(v);
+        const auto r0 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false), r1 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        v = __hiloint2double(r1[0], r0[0]) + __hiloint2double(r1[1], r0[1]);
+    }
+    {   // the two halves of the wave
+        const int lo = __double2loint(v), hi = __double2hiint(v);
+        const auto r0 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false), r1 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        v = __hiloint2double(r1[0], r0[0]) + __hiloint2double(r1[1], r0[1]);
+    }
+    return v;
+}
+
+// lower lanes of the level: lo + partner's lo ; upper lanes: hi + partner's hi
+template <int MASK, bool XOR4 = false>
+__device__ __forceinline__ double lane_pair_split(double lo, double hi, bool up)
+{
+    if constexpr (MASK == 32 || MASK == 16) {
+        (void)up;
+        int a0 = __double2loint(lo), a1 = __double2hiint(lo), b0 = __double2loint(hi), b1 = __double2hiint(hi);
+        if constexpr (MASK == 32) {
+            const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false), r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+            return __hiloint2double(r1[0], r0[0]) + __hiloint2double(r1[1], r0[1]);
+        } else {
+            const auto r0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false), r1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+            return __hiloint2double(r1[0], r0[0]) + __hiloint2double(r1[1], r0[1]);
+        }
+    } else {
+        const double send = up ? lo : hi, keep = up ? hi : lo;
+        return keep + lane_pair_value<MASK, XOR4>(send);
+    }
+}
+template <int N, int MASK, int LOW>
+__device__ __forceinline__ void colsum_fold(const double (&v)[N], int lane, int base, int nv, double &o0, double &o1, int &obase, int &onv)
+{
+    if constexpr (MASK < LOW) {
+        static_assert(N <= 2, "colsum_fold: more than two columns left per lane");
+        o0 = v[0]; o1 = (N > 1) ? v[N > 1 ? 1 : 0] : 0.0; obase = base; onv = nv;
+    } else if constexpr (N == 1) {
+        double w[1];
+        if constexpr (MASK >= 16) w[0] = v[0] + __shfl_xor(v[0], MASK, 64);
+        else w[0] = v[0] + lane_pair_value<MASK, (LOW > 1)>(v[0]);
+        colsum_fold<1, MASK / 2, LOW>(w, lane, base, (lane & MASK) ? 0 : nv, o0, o1, obase, onv);
+    } else {
+        constexpr int H = (N + 1) / 2;
+        const bool up = (lane & MASK) != 0;
+        double w[H];
+#pragma unroll
+        for (int i = 0; i < H; i++) w[i] = lane_pair_split<MASK, (LOW > 1)>(v[i], (i + H < N) ? v[(i + H < N) ? i + H : 0] : 0.0, up);
+        colsum_fold<H, MASK / 2, LOW>(w, lane, base + (up ? H : 0), up ? max(nv - H, 0) : min(nv, H), o0, o1, obase, onv);
+    }
+}
+
 // Next slice ticket of the workgroup, wave-uniform by construction: EVERY lane adds 1 to the LDS counter (the
 // compiler folds the 64 adds into one ds_add_rtn of 64 by the first active lane), so there is no divergent branch
 // in the source, the old value is a multiple of 64 whichever lane's return is read, and the ticket old / 64 lives in
@@ -255,8 +371,31 @@ __device__ __forceinline__ int take_ticket_ends(int *ticket, int from_back, int 
 // SP (1, 2 or 4): ranks above 32.  The factor rows have RT = R * SP columns; SP neighbouring lanes share a task, lane
 // share hp holding columns [hp R, (hp + 1) R) of the major's row, of the accumulators and of every gathered row.  A
 // slice still has 64 tasks: the wave runs it as SP sub-slices of 64 / SP tasks, one after the other.
+// The workgroup's sums of its slices' column-sum rows (SweepSide::csl, written by the gene side of the VB sweep), in list
+// order: one wave, lane c owns columns c and c + 64.  The workgroup's slices are a contiguous id range (slices are
+// numbered in processing order), so are their rows.  Called once the rows are complete and visible: behind a
+// __syncthreads() that follows the side that wrote them (workgroup scope: the same CU stored them).
+template <int RT>
+__device__ __forceinline__ void colsum_finish(const SweepSide &A, int wg, int lane)
+{
+    const int s0 = A.seg_ptr[A.wg_seg0[wg]], s1 = A.seg_ptr[A.wg_seg0[wg + 1]];
+    const int cn = s1 - s0;
+    const double *rows = A.csl + (size_t)s0 * RT;
+    for (int col = lane; col < RT; col += 64) {
+        double t = 0.0;
+        for (int q = 0; q < cn; q += 16) {
+            double v[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) v[u] = rows[(size_t)min(q + u, cn - 1) * RT + col];
+#pragma unroll
+            for (int u = 0; u < 16; u++) t += (q + u < cn) ? v[u] : 0.0;
+        }
+        A.csum[(size_t)wg * RT + col] = t;                 // (a workgroup without slices leaves 0: the update adds all n_wg rows)
+    }
+}
+
 template <int R, bool WIDE, bool LOGTERM, int NT, int EV = 1, int SP = 1>
-__device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restrict__ ldsG)
+__device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restrict__ ldsG, const SweepSide *job = nullptr)
 {
     constexpr int RT = R * SP;
     constexpr int TL = 64 / SP;                            // tasks per sub-slice
@@ -270,6 +409,16 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
     if (S.dbg && lane == 0) S.dbg[(size_t)wg * (2 + 2 * (NT / 64)) + 2 + 2 * wave] = __builtin_amdgcn_s_memrealtime();
     if (S.dbg && threadIdx.x == 0) S.dbg[(size_t)wg * (2 + 2 * (NT / 64))] = __builtin_amdgcn_s_memrealtime();
     double ev_wg = 0.0;                                    // this workgroup's evidence, summed in list order (thread 0)
+    // CS: the gene side of the VB sweep also leaves sum_i sw_ik = sum over tasks of F_k acc_k (S.csl / S.csum), which lets
+    // ONE launch run both posterior updates (k_update2): the H update's rate needs colSums(ew_new) (reference
+    // src/vbnmf_update.cpp:53), and sum_i ew_ik = (n aw + sum_i sw_ik) / bew_k is known without the W update having run.
+    constexpr bool CS = (EV == 1) && LOGTERM;
+    const bool cs_on = CS && S.csl != nullptr;             // (workgroup-uniform)
+    // The per-slice rows are added up per workgroup by colsum_finish(): NOT here -- their read-back is a global round trip,
+    // and inside this side's chunk ends it held the whole workgroup for 3 us at rank 10 and 14 us at rank 20 (round 5,
+    // profiles/r05_pair_ab.txt).  k_sweep hands the job to the CELL side, whose wave 1 runs it when it has run out of
+    // slices, in front of the barrier that waits for the slower waves anyway.
+    bool job_pending = job != nullptr && job->csl != nullptr;   // (workgroup-uniform)
     const int from_back = __builtin_amdgcn_readfirstlane((int)(wave >= (NT / 64) - S.pull_ends));   // the youngest waves (take_ticket_ends)
     double *ev_slot = reinterpret_cast<double *>(reinterpret_cast<char *>(ldsG) + kLdsEvBase);
     int *ticket = reinterpret_cast<int *>(reinterpret_cast<char *>(ldsG) + kLdsCtrBase);
@@ -306,6 +455,8 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
             const int ng = S.slice_width[s] >> 2;
             const int64_t off = S.slice_off[s];
             double ev = 0.0;                               // the lane's evidence contribution over the sub-slices
+            double cs0 = 0.0, cs1 = 0.0;                   // (CS) this lane's finished column sums of the slice ...
+            int cs_base = 0, cs_nv = 0;                    // ... their first column and how many of them it holds
 #pragma unroll 1
             for (int sub = 0; sub < SP; sub++) {
             const int tlane = sub * TL + tl;               // the task's lane in the slice's lane-interleaved storage
@@ -337,7 +488,7 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
                 const int ngf = (EV == 3) ? 0 : min(ng, (S.slice_fast[s] & 0xFFFF) >> 2);      // groups inside the leading stretch of ones
                 int g = 0;
                 for (; g < ngf; g++) {
-                    const Group4 a = unpack4<R>(E[(size_t)g * 64], share);
+                    const Group4 a = unpack4<R>(ld_stream(E + (size_t)g * 64), share);
                     lds_row<R>(ldsG, a.o0, g0); sweep_entry<R, false, true, SP>(T, ldsG, g0, 1.0, LOGTERM);
                     lds_row<R>(ldsG, a.o1, g0); sweep_entry<R, false, true, SP>(T, ldsG, g0, 1.0, LOGTERM);
                     if (LOGTERM) renorm_product<R>(T);
@@ -346,7 +497,7 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
                     if (LOGTERM) renorm_product<R>(T);
                 }
                 for (; g < ng; g++) {
-                    const Group4 a = unpack4<R>(E[(size_t)g * 64], share);
+                    const Group4 a = unpack4<R>(ld_stream(E + (size_t)g * 64), share);
                     lds_row<R>(ldsG, a.o0, g0); sweep_entry<R, EV == 3, false, SP>(T, ldsG, g0, (double)a.c0, LOGTERM);
                     lds_row<R>(ldsG, a.o1, g0); sweep_entry<R, EV == 3, false, SP>(T, ldsG, g0, (double)a.c1, LOGTERM);
                     lds_row<R>(ldsG, a.o2, g0); sweep_entry<R, EV == 3, false, SP>(T, ldsG, g0, (double)a.c2, LOGTERM);
@@ -357,7 +508,7 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
             } else if (!WIDE) {
                 double2 g1[R / 2];
                 const uint4 *E = reinterpret_cast<const uint4 *>(S.packed + off) + tlane;
-                Group4 a = unpack4<R>(E[0], share), b = unpack4<R>(E[(size_t)min(1, ng - 1) * 64], share);
+                Group4 a = unpack4<R>(ld_stream(E), share), b = unpack4<R>(ld_stream(E + (size_t)min(1, ng - 1) * 64), share);
                 lds_row<R>(ldsG, a.o0, g0);
                 // FENCE keeps the machine scheduler from sinking a row's LDS reads down to their first
                 // use: the reads of entry j+1 stay in front of the arithmetic of entry j, which hides them.
@@ -369,7 +520,7 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
 #define VBNMF_TRIP(MODE, PIN)                                                                     \
                 {                                                                                 \
                     /* the next trip's groups; past the end: the last group again (an odd one is the tail's) */ \
-                    const uint4 ec = E[(size_t)min(2 * p + 2, ng - 1) * 64], ed = E[(size_t)min(2 * p + 3, ng - 1) * 64]; \
+                    const uint4 ec = ld_stream(E + (size_t)min(2 * p + 2, ng - 1) * 64), ed = ld_stream(E + (size_t)min(2 * p + 3, ng - 1) * 64); \
                     lds_row<R>(ldsG, a.o1, g1); VBNMF_FENCE();                                    \
                     VBNMF_ENTRY(MODE, g0, a.c0);                                                   \
                     lds_row<R>(ldsG, a.o2, g0); VBNMF_FENCE();                                    \
@@ -423,8 +574,8 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
                 const double2 *V = reinterpret_cast<const double2 *>(S.wval + off) + tlane * 2;
                 const uint32_t rowb = (uint32_t)S.row_slots * 16u;     // bytes per staged row
                 for (int g = 0; g < ng; g++) {
-                    const uint4 c = E[(size_t)g * 64];
-                    const double2 v0 = V[(size_t)g * 128], v1 = V[(size_t)g * 128 + 1];
+                    const uint4 c = ld_stream(E + (size_t)g * 64);
+                    const double2 v0 = ld_stream(V + (size_t)g * 128), v1 = ld_stream(V + (size_t)g * 128 + 1);
                     lds_row<R>(ldsG, c.x * rowb + share, g0);
                     lds_row<R>(ldsG, c.y * rowb + share, g1);
                     sweep_entry<R, EV == 3, false, SP>(T, ldsG, g0, v0.x, LOGTERM);
@@ -455,24 +606,39 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
                 ev += evt;
             }
             if (EV == 2 && M != kIdle && hp == 0) ev += T.lsum;
-            }                                              // sub-slices
+            if (CS && cs_on) {                             // column sums of F .* acc over the sub-slice's tasks
+                double c[R];
 #pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) ev += __shfl_down(ev, d, 64);
-            if (lane == 0) ev_slot[i] = ev;                // this slice's evidence partial
+                for (int k = 0; k < R; k++) c[k] = (M != kIdle) ? T.F[k] * T.acc[k] : 0.0;
+                double o0, o1;
+                colsum_fold<R, 32, SP>(c, lane, 0, R, o0, o1, cs_base, cs_nv);
+                cs0 += o0; cs1 += o1;
+            }
+            }                                              // sub-slices
+            ev = wave_sum_dpp(ev);                         // (every lane holds the slice's evidence partial)
+            if (lane == 0) ev_slot[i] = ev;
+            if (CS && cs_on) {                             // ... and its row of column sums (added up by colsum_finish)
+                double *row = S.csl + (size_t)s * RT + hp * R + cs_base;
+                if (cs_nv >= 1) row[0] = cs0;
+                if (cs_nv >= 2) row[1] = cs1;
+            }
         }
         // end of the chunk: add its slots in list order (wave 0: lane-strided, then a fixed shuffle tree)
+        if (job_pending) {                                 // the other side's column sums, by a wave that is out of slices
+            if (wave == 1) colsum_finish<RT>(*job, wg, lane);
+            job_pending = false;
+        }
         __syncthreads();
         if (wave == 0) {
             double t = 0.0;
             for (int q = lane; q < cn; q += 64) t += ev_slot[q];
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) t += __shfl_down(t, d, 64);
-            ev_wg += t;                                    // meaningful in thread 0
+            ev_wg += wave_sum_dpp(t);
             if (lane == 0) *ticket = 0;
         }
         __syncthreads();
         }
     }
+    if (job_pending && wave == 1) colsum_finish<RT>(*job, wg, lane);      // (no chunk end on this side: a workgroup without slices)
     if (S.dbg && lane == 0) S.dbg[(size_t)wg * (2 + 2 * (NT / 64)) + 3 + 2 * wave] = __builtin_amdgcn_s_memrealtime();
     if (threadIdx.x == 0) {
         S.epart[wg] = ev_wg;                               // one evidence partial per workgroup and side
@@ -485,8 +651,8 @@ __global__ __launch_bounds__(NT) void k_sweep(const SweepSide A, const SweepSide
 {
     extern __shared__ double2 ldsG[];
     if (A.stop && *A.stop) return;               // the driver loop has ended: leave the statistics as they are
-    sweep_side<R, WIDE, true, NT, 1, SP>(A, ldsG);      // lanes own genes: statistics sw + the sum x log(wth)
-    sweep_side<R, WIDE, false, NT, 1, SP>(B, ldsG);     // lanes own cells: statistics sh
+    sweep_side<R, WIDE, true, NT, 1, SP>(A, ldsG);      // lanes own genes: statistics sw + the sum x log(wth) (+ rows of column sums)
+    sweep_side<R, WIDE, false, NT, 1, SP>(B, ldsG, &A); // lanes own cells: statistics sh (+ the gene side's column sums added up)
 }
 
 // One side alone (ML-NMF: its H and W updates are sequential, reference R/factorize.R:8-24, so each needs its
@@ -561,12 +727,7 @@ constexpr int kUpdateThreads = 1024;
 constexpr int kStageIds = 14336;       // task ids of a block's majors staged in LDS by k_update (56 KB) ...
 constexpr int kStagePtr = 2048;        // ... and their pointer stretch (8 KB); a block with more falls back to global reads
 
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d, 64);
-    return v;                                     // valid in lane 0
-}
+__device__ __forceinline__ double wave_sum(double v) { return wave_sum_dpp(v); }     // (valid in every lane; no LDS round trips)
 
 // Column sums of a block-partials table bp[nb][ncol] (nb <= 256) into out[0..ncol) (LDS or
 // global): wave w takes columns w, w+nwaves, ...; lane l adds rows l, l+64, ... in order.
@@ -591,6 +752,21 @@ __device__ __forceinline__ void bp_colsums2(const double *__restrict__ bpA, cons
         for (int b = lane; b < nb; b += 64) { sa += bpA[(size_t)b * ncol + c]; sb += bpB[(size_t)b * ncol + c]; }
         sa = wave_sum(sa); sb = wave_sum(sb);
         if (lane == 0) { outA[c] = sa; outB[c] = sb; }
+    }
+}
+
+// Three tables at once (k_update2's prologue): A and B have ncol columns, C has ncolC <= ncol; nbC rows for C.
+__device__ __forceinline__ void bp_colsums3(const double *__restrict__ bpA, const double *__restrict__ bpB, int nb, int ncol,
+                                            const double *__restrict__ bpC, int nbC, int ncolC,
+                                            double *outA, double *outB, double *outC, int nthreads)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = nthreads >> 6;
+    for (int c = wave; c < ncol; c += nw) {
+        double sa = 0.0, sb = 0.0, sc = 0.0;
+        for (int b = lane; b < nb; b += 64) { if (bpA) sa += bpA[(size_t)b * ncol + c]; sb += bpB[(size_t)b * ncol + c]; }
+        if (c < ncolC) for (int b = lane; b < nbC; b += 64) sc += bpC[(size_t)b * ncolC + c];
+        sa = wave_sum_dpp(sa); sb = wave_sum_dpp(sb); sc = wave_sum_dpp(sc);
+        if (lane == 0) { if (bpA) outA[c] = sa; outB[c] = sb; if (c < ncolC) outC[c] = sc; }
     }
 }
 
@@ -657,8 +833,10 @@ constexpr int kEvSlots = 1024;
 #ifdef VBNMF_ABL_STAMPS                                       /* instrumented builds only (profiles/ubench/r04/update_stamps.sh) */
 __device__ unsigned long long g_upd_stamps[2 * kUpdateBlocks * 12];
 #define UPD_STAMP(i) do { if (threadIdx.x == 0 && !fold.control_only) g_upd_stamps[((size_t)side * kUpdateBlocks + blockIdx.x) * 12 + (i)] = wall_clock64(); } while (0)
+#define UPD2_STAMP(i) do { if (threadIdx.x == 0) g_upd_stamps[((size_t)blockIdx.x) * 12 + (i)] = wall_clock64(); } while (0)   /* k_update2: the first table */
 #else
 #define UPD_STAMP(i) do { } while (0)
+#define UPD2_STAMP(i) do { } while (0)
 #endif
 
 template <int R>
@@ -857,6 +1035,257 @@ __global__ __launch_bounds__(kUpdateThreads) void k_update(
         o[R] = st; o[R + 1] = sl;
     }
     UPD_STAMP(7);
+}
+
+// ------------------------------------------------------------------------------------
+// Both posterior updates in ONE launch (unpartitioned engines; round 5).  The H update's rate needs colSums(ew_new)
+// (reference src/vbnmf_update.cpp:53 -- `ew` is updated before `beh`, :44 before :53), which used to force a kernel
+// boundary between the two updates.  But sum_i ew_ik = sum_i (aw + sw_ik) / bew_k = (n aw + sum_i sw_ik) / bew_k, and
+// the gene side of the sweep now leaves sum_i sw_ik (SweepSide::csum: per-slice sums by a fixed tree, added per
+// workgroup in list order -- no atomics, bit-reproducible run to run), so every block knows both rates from the start:
+//   bew_k = aw/bw + rowSums(eh_in)_k                    :40-43   (block partials of the previous H update)
+//   beh_k = ah/bh + (n aw + sum_i sw_ik) / bew_k        :50-53   (the NEW ew's column sums, as the reference orders it)
+// and works through its genes and its cells with no hand-off in between.  The gene side's results are the two-launch
+// form's bit for bit; beh_k differs from it by the rounding of one sum (the two-launch form adds the n rounded quotients
+// ew_ik; this one divides the sum): ~1e-16 relative.  The evidence's cross term keeps using the sum of the stored ew (bpW).
+//
+// The block's work is a TABLE the host cuts when the engine is made (engine.hip: build_update_table), one row of
+// `stride4` 16-byte words per block, the same shape for every block, so its load heads the kernel and depends on nothing:
+//   visits  [RB][V][3]   thread row `row` makes visits (row, 0), (row, 1), ...: {side << 31 | major - the block's first major
+//                        of that side, q0, q1} = the major's stretch of the ids below; 0xFFFFFFFF ends a row's list.
+//                        The block's majors of BOTH sides are dealt to the rows longest-processing-time first (cost = rounds of
+//                        16 task rows + the posterior's arithmetic): a gene with 80 tasks no longer holds its block
+//                        while the other rows idle (k_update walks the majors in index order: in-kernel stamps, rank 10:
+//                        thread 0 done at 23.6 us, the block's last thread at 33).
+//   ids     [..]         the task ids of the block's majors (the inverse index's stretches, copied)
+// The time line of the first version (index order, the inverse index staged through four dependent round trips; rank 10,
+// profiles/r05_update2_stamps.txt): 6.0 us until the staging loads are out, 3.8 column sums, 0.9 + 3.6 control step,
+// 11.8 + 11.8 the two stretches of thread 0, 9.3 waiting for the block's slowest thread, 1.7 reduction = 49 us.
+// Block partials out: W.bp[block][0..R+2), H.bp[block][0..R+2) as k_update; both tables alternate by step (nothing a
+// block reads is written in the same launch).
+// ------------------------------------------------------------------------------------
+struct UpdSide {
+    const double *part;            // [n_tasks][R] per-task partial statistics of this side's sweep
+    int64_t nmaj;
+    double *l, *ll, *e, *d;        // state arrays of the factor
+    double *bp;                    // [nb][R+2] block partials written by this launch
+    const double *bp_prev;         // ... of the previous update of this factor (H: rowSums(eh_in); W: the control step's colSums(ew))
+};
+struct UpdTable {
+    const uint4 *tab;              // [blocks][stride4]
+    int32_t stride4;               // 16-byte words per block (<= kUpdTabWords / 4)
+    int32_t V;                     // visits per thread row (the longest list)
+    int32_t ids_off;               // word offset of the ids inside a block's row
+};
+constexpr int kUpdTabWords = 16384;        // LDS copy of a block's row of the table: 64 KB
+
+
+// The visits of one thread row to the majors of one side (the row's list holds its genes first, then its cells): column k
+// of every visited major -- gather of the task partials, Gamma posterior, geometric mean, evidence terms (k_update's body).
+template <int R>
+__device__ __forceinline__ int posterior_visits(const UpdSide &S, int64_t m0, const uint32_t *vis, int v, int V, uint32_t side,
+                                                const uint32_t *ids, int k, int r, double a, double ab, double be, double lbe,
+                                                double lga, double fudge, double &ve, double &vt, double &vl)
+{
+    for (; v < V; v++) {
+        const uint32_t code = vis[3 * v];
+        if (code == 0xFFFFFFFFu || (code >> 31) != side) break;
+        const int64_t M = m0 + (int64_t)(code & 0x7FFFFFFFu);
+        const int q0 = (int)vis[3 * v + 1], q1 = (int)vis[3 * v + 2];
+        const size_t o = (size_t)M * R + k;
+        if (k < r) {
+            const double s = task_sum_lds(S.part, ids, q0, q1, R, k);
+            const double al = a + S.l[o] * s;
+            const double ev = al / be;
+            const double dv = al / be / be;
+            double psi, lgam;
+            dev_psi_lgamma(al, &psi, &lgam);
+            if (!(al > 0.0)) { psi = __builtin_nan(""); lgam = __builtin_nan(""); }
+            const double tmp = exp(psi) / be;
+            const double ln = (tmp > fudge ? tmp : fudge);
+            const double lg = log(ln);
+            ve += ev;
+            vt += -ab * ev + lga + al * (1.0 - lbe) + lgam;
+            vl += lg;
+            S.l[o] = ln; S.ll[o] = ln * lg; S.e[o] = ev; S.d[o] = dv;
+        } else {
+            S.l[o] = 0.0; S.ll[o] = 0.0; S.e[o] = 0.0; S.d[o] = 0.0;
+        }
+    }
+    return v;
+}
+
+template <int R>
+__global__ __launch_bounds__(kUpdateThreads) void k_update2(
+    const UpdSide W, const UpdSide H, const UpdTable T, int r, int nb, const double *__restrict__ csum, int ncs,
+    double aw, double bw, double ah, double bh, double fudge, const LoopCtl *__restrict__ ctl, const ControlFold fold)
+{
+    constexpr int RB = kUpdateThreads / R;
+    __shared__ double s_other[R + 2], s_cs[R + 2], sW[R + 2], s_hy[4];
+    __shared__ double s_red[6][kUpdateThreads];
+    __shared__ uint4 s_tab4[kUpdTabWords / 4];
+    __shared__ int s_stop;
+    const uint32_t *s_tab = reinterpret_cast<const uint32_t *>(s_tab4);
+    const int t = threadIdx.x;
+    UPD2_STAMP(0);
+    // the block's row of the table: loads issued first thing, parked in registers, written to LDS behind the other loads
+    uint4 tb[4];
+    {
+        const uint4 *src = T.tab + (size_t)blockIdx.x * T.stride4;
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int q = t + u * kUpdateThreads; if (q < T.stride4) tb[u] = src[q]; }
+    }
+    const int64_t perW = (W.nmaj + gridDim.x - 1) / gridDim.x, perH = (H.nmaj + gridDim.x - 1) / gridDim.x;
+    const int64_t w0 = min(W.nmaj, (int64_t)blockIdx.x * perW), h0 = min(H.nmaj, (int64_t)blockIdx.x * perH);
+    int stopped = 0;
+    UPD2_STAMP(1);
+    if (fold.prev) {
+        // ---- the folded control step (k_update's, statement by statement; the cell side's sums come from H.bp_prev) ----
+        const LoopCtl *pv = fold.prev;
+        const int was_stopped = pv->stop;
+        double part = 0.0;
+        if (fold.do_control) for (int64_t q = t; q < fold.nepart; q += kUpdateThreads) part += fold.epart[q];
+        bp_colsums3(W.bp_prev, H.bp_prev, nb, R + 2, csum, ncs, R, sW, s_other, s_cs, kUpdateThreads);
+        UPD2_STAMP(8);
+        if (was_stopped) {                       // a step queued past the stop: the control block and both partial tables travel on
+            if (blockIdx.x == 0 && t == 0) *fold.next = *pv;
+            if (t < R + 2) {
+                W.bp[(size_t)blockIdx.x * (R + 2) + t] = W.bp_prev[(size_t)blockIdx.x * (R + 2) + t];
+                H.bp[(size_t)blockIdx.x * (R + 2) + t] = H.bp_prev[(size_t)blockIdx.x * (R + 2) + t];
+            }
+            return;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int q = t + u * kUpdateThreads; if (q < T.stride4) s_tab4[q] = tb[u]; }
+        const double data = block_sum(part, s_red[0]);       // (two barriers: sW, s_other, s_cs and the table are complete behind it)
+        UPD2_STAMP(9);
+        if (t < 2) {
+            if (t == 0) for (int q = 0; q < 4; q++) s_hy[q] = pv->hyper[q];
+            int reason = 0, it = pv->it;
+            double lkh = pv->lkh, new_lk0 = pv->lk0;
+            double st[4] = {pv->stats[0], pv->stats[1], pv->stats[2], pv->stats[3]};
+            if (fold.do_control) {
+                double cross = 0.0, sew = 0.0, seh = 0.0;
+                for (int k = 0; k < r; k++) { cross += sW[k] * s_other[k]; sew += sW[k]; seh += s_other[k]; }
+                const double U = -cross - data - fold.lgx + sW[R] + s_other[R];
+                lkh = U / (fold.n * fold.m_global);
+                st[0] = sW[R + 1] / (fold.n * r); st[1] = s_other[R + 1] / (fold.m_global * r);
+                st[2] = sew / (fold.n * r); st[3] = seh / (fold.m_global * r);
+                it = pv->it + 1;
+                if (it > pv->n0 && it % pv->dn == 0) {
+                    if (dev_hyper_update_pair(pv->flags, st, s_hy, t)) reason = 3;
+                }
+                if (t == 0 && !reason) {
+                    const double lk0 = pv->lk0;
+                    if (lkh != lkh) reason = 1;
+                    else if (it > 1 && it > pv->n0 && lkh >= lk0 && fabs(1.0 - lkh / lk0) < pv->tol) reason = 2;
+                    else { new_lk0 = lkh; if (it >= pv->max_it) reason = 4; }
+                }
+            }
+            if (t == 0) {
+                s_stop = reason != 0;
+                if (blockIdx.x == 0) {
+                    LoopCtl nx = *pv;
+                    nx.it = it; nx.lkh = lkh; nx.lk0 = new_lk0;
+                    for (int q = 0; q < 4; q++) { nx.stats[q] = st[q]; nx.hyper[q] = s_hy[q]; }
+                    if (reason) { nx.reason = reason; nx.stop = 1; }
+                    *fold.next = nx;
+                    if (fold.do_control) {
+                        if (fold.history) {
+                            double *h = fold.history + (size_t)(it - 1) * 9;
+                            h[0] = lkh;
+                            for (int q = 0; q < 4; q++) { h[1 + q] = st[q]; h[5 + q] = s_hy[q]; }
+                        }
+                        double *oh = fold.out_host;
+                        oh[0] = lkh;
+                        for (int q = 0; q < 4; q++) { oh[1 + q] = st[q]; oh[8 + q] = s_hy[q]; }
+                        oh[12] = new_lk0;
+                        oh[5] = (double)it;
+                        __threadfence_system();
+                        reinterpret_cast<volatile double *>(oh)[6] = (double)reason;
+                        reinterpret_cast<volatile double *>(oh)[7] = (double)it;
+                    }
+                }
+            }
+        }
+        UPD2_STAMP(10);
+        __syncthreads();
+        if (s_stop) {                            // the loop ends here: no update, the partials' rows travel on (as above)
+            if (t < R + 2) {
+                W.bp[(size_t)blockIdx.x * (R + 2) + t] = W.bp_prev[(size_t)blockIdx.x * (R + 2) + t];
+                H.bp[(size_t)blockIdx.x * (R + 2) + t] = H.bp_prev[(size_t)blockIdx.x * (R + 2) + t];
+            }
+            return;
+        }
+        aw = s_hy[0]; bw = s_hy[1]; ah = s_hy[2]; bh = s_hy[3];
+    } else {
+        if (ctl) {                               // device-driven loop without the fold: hyper-parameters from the control block
+            stopped = ctl->stop;
+            aw = ctl->hyper[0]; bw = ctl->hyper[1]; ah = ctl->hyper[2]; bh = ctl->hyper[3];
+        }
+        bp_colsums3(nullptr, H.bp_prev, nb, R + 2, csum, ncs, R, nullptr, s_other, s_cs, kUpdateThreads);
+        if (stopped) {                           // (both tables alternate by launch: the rows travel on)
+            if (t < R + 2) {
+                W.bp[(size_t)blockIdx.x * (R + 2) + t] = W.bp_prev[(size_t)blockIdx.x * (R + 2) + t];
+                H.bp[(size_t)blockIdx.x * (R + 2) + t] = H.bp_prev[(size_t)blockIdx.x * (R + 2) + t];
+            }
+            return;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int q = t + u * kUpdateThreads; if (q < T.stride4) s_tab4[q] = tb[u]; }
+        __syncthreads();
+    }
+    UPD2_STAMP(2);
+    double psi_a, lg_a;
+    dev_psi_lgamma(aw, &psi_a, &lg_a);
+    const double lgaW = -lg_a + aw * log(aw / bw);   // reference src/vbnmf_update.cpp:82
+    dev_psi_lgamma(ah, &psi_a, &lg_a);
+    const double lgaH = -lg_a + ah * log(ah / bh);   // :87
+
+    const int row = t / R, k = t - row * R;
+    const int kc = k < R ? k : 0;
+    const double beW = aw / bw + s_other[kc];                                   // :40-43
+    const double beH = ah / bh + ((double)W.nmaj * aw + s_cs[kc]) / beW;        // :50-53 on the NEW ew's column sums
+    const double lbeW = log(beW), lbeH = log(beH);
+    double acc6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // sum e, sum term, sum log l of the gene side; the same of the cell side
+    UPD2_STAMP(3);
+    if (row < RB) {
+        // a row's visits to genes come first, its visits to cells behind them: inside each loop the factor's arrays are the
+        // same for every lane (scalar base addresses)
+        const uint32_t *vis = s_tab + (size_t)row * T.V * 3;
+        const uint32_t *ids = s_tab + T.ids_off;
+        int v = 0;
+        v = posterior_visits<R>(W, w0, vis, v, T.V, 0u, ids, k, r, aw, aw / bw, beW, lbeW, lgaW, fudge, acc6[0], acc6[1], acc6[2]);
+        UPD2_STAMP(11);
+        v = posterior_visits<R>(H, h0, vis, v, T.V, 1u, ids, k, r, ah, ah / bh, beH, lbeH, lgaH, fudge, acc6[3], acc6[4], acc6[5]);
+    }
+    UPD2_STAMP(4);
+#pragma unroll
+    for (int q = 0; q < 6; q++) s_red[q][t] = acc6[q];
+    __syncthreads();
+    UPD2_STAMP(5);
+    constexpr int P2 = (RB <= 32) ? 32 : (RB <= 64) ? 64 : (RB <= 128) ? 128 : (RB <= 256) ? 256 : 512;
+    for (int h = P2 / 2; h >= 1; h >>= 1) {
+        if (row < h && row + h < RB) {
+#pragma unroll
+            for (int q = 0; q < 6; q++) s_red[q][t] += s_red[q][t + h * R];
+        }
+        __syncthreads();
+    }
+    UPD2_STAMP(6);
+    double *oW = W.bp + (size_t)blockIdx.x * (R + 2), *oH = H.bp + (size_t)blockIdx.x * (R + 2);
+    if (t < R) { oW[t] = s_red[0][t]; oH[t] = s_red[3][t]; }
+    if (t == 0) {
+        double st = 0.0, sl = 0.0;
+        for (int q = 0; q < R; q++) { st += s_red[1][q]; sl += s_red[2][q]; }
+        oW[R] = st; oW[R + 1] = sl;
+    }
+    if (t == 64) {
+        double st = 0.0, sl = 0.0;
+        for (int q = 0; q < R; q++) { st += s_red[4][q]; sl += s_red[5][q]; }
+        oH[R] = st; oH[R + 1] = sl;
+    }
+    UPD2_STAMP(7);
 }
 
 // State load (set_state): ll = l*log(l) and the block partials of e's column sums, same

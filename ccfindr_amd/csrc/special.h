@@ -126,7 +126,9 @@ __host__ __device__ __forceinline__ double dev_log(double x)
     return dk * ln2_hi - ((hfsq - (s * (hfsq + Rp) + dk * ln2_lo)) - f);
 }
 
-// psi(x) and ln Gamma(x) together, x > 0 (x up to ~1e25; the engine's arguments are count sums).
+// psi(x) and ln Gamma(x) together, x > 0.  D(x) ~ x^10 overflows fp64 past x ~ 6e30, so from x = 1e25 on the shift is
+// left out (there the asymptotic series at y = x is exact to the last bit by itself; the engine's arguments are a shape plus
+// a count sum, far below -- the guard makes the routine total, it is two selects).
 // Both use the same upward shift by 10,
 //     psi(x)     = psi(x+10)      - D'(x)/D(x)
 //     lnGamma(x) = lnGamma(x+10)  - ln D(x),          D(x) = x (x+1) ... (x+9),
@@ -143,7 +145,8 @@ __host__ __device__ __forceinline__ void dev_psi_lgamma(double x, double *psi, d
         Dp = fma(Dp, t, D);
         D = D * t;
     }
-    const double y = x + 10.0;
+    const bool big = x > 1e25;                            // no shift: D would overflow from ~6e30 on
+    const double y = big ? x : x + 10.0;
     const double ly = dev_log(y);
     const double yi = sp_rcp(y), y2 = yi * yi;
     // psi(y) = ln y - 1/(2y) - sum B_2k / (2k y^2k)
@@ -154,7 +157,7 @@ __host__ __device__ __forceinline__ void dev_psi_lgamma(double x, double *psi, d
     sp = fma(-y2, sp, 1.0 / 252);
     sp = fma(-y2, sp, 1.0 / 120);
     sp = fma(-y2, sp, 1.0 / 12);
-    *psi = (ly - 0.5 * yi - y2 * sp) - dev_div(Dp, D);
+    *psi = (ly - 0.5 * yi - y2 * sp) - (big ? 0.0 : dev_div(Dp, D));
     // lnGamma(y) = (y - 1/2) ln y - y + ln(2 pi)/2 + sum B_2k / (2k (2k-1) y^(2k-1))
     double sg = 1.0 / 156;
     sg = fma(-y2, sg, 691.0 / 360360);
@@ -164,7 +167,7 @@ __host__ __device__ __forceinline__ void dev_psi_lgamma(double x, double *psi, d
     sg = fma(-y2, sg, 1.0 / 360);
     sg = fma(-y2, sg, 1.0 / 12);
     const double half_log_2pi = 0.91893853320467274178;
-    *lgam = (((y - 0.5) * ly - y) + half_log_2pi + yi * sg) - dev_log(D);
+    *lgam = (((y - 0.5) * ly - y) + half_log_2pi + yi * sg) - (big ? 0.0 : dev_log(D));
 }
 
 }  // namespace vbnmf

@@ -69,6 +69,33 @@ def _unit_views(seg, base, n, m, r):
             "dw": seg.array(base + nr + rm, (n, r)), "dh": seg.array(base + 2 * nr + rm, (r, m))}
 
 
+def _any_failed(flag, world, group, device):
+    """True on every process when `flag` is set on any: one all-reduce that every process of the group reaches (it is also
+    a barrier).  A single process just returns its own flag."""
+    if world <= 1:
+        return bool(flag)
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([1.0 if flag else 0.0], dtype=torch.float64)
+    if dist.get_backend(group) == "nccl":
+        t = t.to(torch.device("cuda", device))
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return float(t.cpu()[0]) > 0.0
+
+
+def _remove_files(paths):
+    """Unlink what this process put into the node's memory file system: finished segments, the `.part` a failed cut left,
+    its failure note.  tmpfs pages are RAM until the name AND the mappings are gone."""
+    import os
+    for path in list(paths):
+        for cand in (path, path + ".part"):
+            try:
+                os.unlink(cand)
+            except (FileNotFoundError, IsADirectoryError):
+                pass
+    del paths[:]
+
+
 def vb_factorize_sharded(mat, ranks=2, nrun=1, verbose=0, initializer="random", Itmax=10000,
                          hyper_update=(True, True, True, True), gamma_a=1, gamma_b=1, Tol=1e-5,
                          hyper_update_n0=10, hyper_update_dn=1, fudge=None, unif_stop=True, seed=0,
@@ -197,118 +224,151 @@ def vb_factorize_sharded(mat, ranks=2, nrun=1, verbose=0, initializer="random", 
     detail = {} if timings is not None else None
     tick = time.perf_counter
     cleanup = []                                         # files this process created (unlinked behind the next barrier)
+    layout_error = None
     if native:
-        import threading
-        geoms = sorted({geometry_rank_for(r, bundle["classes"]) or int(r) for r in bundle["ranks"]})
-        pieces = [(g, side) for g in geoms for side in (1, 0)]          # cell side first: it needs no row-major copy of X
-        builder_of = {pc: node_holders[q % len(node_holders)] for q, pc in enumerate(pieces)}
-        n_wg = mine["n_wg"]
-        sharing = world > 1 and len(my_node) > 1
-        seg_name = lambda b, pc: f"vbnmf_{peers[b]['token']}_g{pc[0]}_s{pc[1]}"
-        failed_name = lambda b: f"vbnmf_{peers[b]['token']}_failed"
-        wait_s = float(os.environ.get("VBNMF_WAIT_TIMEOUT_S", "300") or 300)
-        seg_path = lambda b, pc: os.path.join(shm.shm_dir(), seg_name(b, pc))
-        if sharing and any(b == me for b in builder_of.values()):
-            loaders, errors = [], []
+        try:
+            import threading
+            geoms = sorted({geometry_rank_for(r, bundle["classes"]) or int(r) for r in bundle["ranks"]})
+            pieces = [(g, side) for g in geoms for side in (1, 0)]          # cell side first: it needs no row-major copy of X
+            builder_of = {pc: node_holders[q % len(node_holders)] for q, pc in enumerate(pieces)}
+            n_wg = mine["n_wg"]
+            sharing = world > 1 and len(my_node) > 1
+            seg_name = lambda b, pc: f"vbnmf_{peers[b]['token']}_g{pc[0]}_s{pc[1]}"
+            failed_name = lambda b: f"vbnmf_{peers[b]['token']}_failed"
+            wait_s = float(os.environ.get("VBNMF_WAIT_TIMEOUT_S", "300") or 300)
+            seg_path = lambda b, pc: os.path.join(shm.shm_dir(), seg_name(b, pc))
+            if sharing and any(b == me for b in builder_of.values()):
+                loaders, errors = [], []
 
-            def load(pc):                                # this process's own device copy, beside the cut of the next piece
+                def load(pc):                                # this process's own device copy, beside the cut of the next piece
+                    try:
+                        t0 = tick()
+                        X.preload_layout(pc[1], pc[0], n_wg, device)
+                        if detail is not None:
+                            detail[f"preload_side{pc[1]}_s"] = tick() - t0
+                    except BaseException as exc:             # noqa: BLE001
+                        errors.append(exc)
+
+                # The peers of this node wait for these cuts and their cores idle: the builder takes its share of the node's cores
+                # for the duration (the library's default stops at 32 threads per process, a cap meant for ranks that all work at
+                # once).  Layouts and cell order do not depend on the thread count.
+                from .engine import host_threads, set_host_threads
+                builders_here = max(1, len(set(b for b in builder_of.values() if b in my_node)))
                 try:
-                    t0 = tick()
-                    X.preload_layout(pc[1], pc[0], n_wg, device)
-                    if detail is not None:
-                        detail[f"preload_side{pc[1]}_s"] = tick() - t0
-                except BaseException as exc:             # noqa: BLE001
-                    errors.append(exc)
-
-            # The peers of this node wait for these cuts and their cores idle: the builder takes its share of the node's cores
-            # for the duration (the library's default stops at 32 threads per process, a cap meant for ranks that all work at
-            # once).  Layouts and cell order do not depend on the thread count.
-            from .engine import host_threads, set_host_threads
-            builders_here = max(1, len(set(b for b in builder_of.values() if b in my_node)))
-            try:
-                cores = len(os.sched_getaffinity(0))
-            except (AttributeError, OSError):
-                cores = os.cpu_count() or 1
-            cores = int(os.environ.get("VBNMF_TEST_NODE_CORES") or 0) or cores        # test hook: pretend the node has this many
-            want = min(128, cores // builders_here)
-            lifted = want > host_threads() and not os.environ.get("VBNMF_HOST_THREADS")
-            if lifted:
-                set_host_threads(want)
-            if detail is not None:
-                detail["cut_threads"] = host_threads()
-            try:
-                X.prepare_async()                        # cell order, then the row-major copy, beside the cut of the cell side
-                for pc in pieces:
-                    if builder_of[pc] != me:
-                        continue
-                    t0 = tick()
-                    X.share_layout(pc[1], pc[0], n_wg, seg_path(me, pc))         # cut INTO the shared file; the name appears when complete
-                    cleanup.append(seg_path(me, pc))
-                    if detail is not None:
-                        detail[f"cut_side{pc[1]}_s"] = tick() - t0
-                    th = threading.Thread(target=load, args=(pc,))
-                    th.start()
-                    loaders.append(th)
-                for th in loaders:
-                    th.join()
-                if errors:
-                    raise errors[0]
-            except BaseException as exc:
-                with open(os.path.join(shm.shm_dir(), failed_name(me)), "w") as fh:   # the peers stop polling and raise
-                    fh.write(f"{type(exc).__name__}: {exc}")
-                cleanup.append(os.path.join(shm.shm_dir(), failed_name(me)))
-                raise
-            finally:
+                    cores = len(os.sched_getaffinity(0))
+                except (AttributeError, OSError):
+                    cores = os.cpu_count() or 1
+                cores = int(os.environ.get("VBNMF_TEST_NODE_CORES") or 0) or cores        # test hook: pretend the node has this many
+                want = min(128, cores // builders_here)
+                lifted = want > host_threads() and not os.environ.get("VBNMF_HOST_THREADS")
                 if lifted:
-                    set_host_threads(0)
-        if sharing:
-            t0 = tick()
-            for pc in pieces:
-                b = builder_of[pc]
-                if b == me:
-                    continue
-                if peers[b]["n_wg"] != n_wg:
-                    raise RuntimeError(f"process {b} cuts layouts for {peers[b]['n_wg']} workgroups, this device wants {n_wg}")
-                t1 = tick()
-                shm.wait_for(seg_name(b, pc), wait_s, failed_name(b))
-                t2 = tick()
-                X.attach_layout(seg_path(b, pc))                 # mapped, not copied
-                t3 = tick()
-                X.preload_layout(pc[1], pc[0], n_wg, device)     # upload it now, beside the wait for the next piece
+                    set_host_threads(want)
                 if detail is not None:
-                    detail[f"wait_side{pc[1]}_s"] = t2 - t1
-                    detail[f"attach_side{pc[1]}_s"] = t3 - t2
-                    detail[f"preload_side{pc[1]}_s"] = tick() - t3
-            if detail is not None:
-                detail["wait_and_attach_s"] = tick() - t0
-        if not sharing and int(concurrent) > 1 and not X.is_shell:
-            # nobody to share with, but several units in flight: cut (and upload) the sweep's layouts once, here, instead of
-            # letting the first units' threads cut the same pair side by side
-            for pc in pieces:
-                X.preload_layout(pc[1], pc[0], n_wg, device)
+                    detail["cut_threads"] = host_threads()
+                try:
+                    X.prepare_async()                        # cell order, then the row-major copy, beside the cut of the cell side
+                    for pc in pieces:
+                        if builder_of[pc] != me:
+                            continue
+                        t0 = tick()
+                        cleanup.append(seg_path(me, pc))                         # (registered first: a failed cut leaves a .part)
+                        X.share_layout(pc[1], pc[0], n_wg, seg_path(me, pc))         # cut INTO the shared file; the name appears when complete
+                        if detail is not None:
+                            detail[f"cut_side{pc[1]}_s"] = tick() - t0
+                        th = threading.Thread(target=load, args=(pc,))
+                        th.start()
+                        loaders.append(th)
+                    for th in loaders:
+                        th.join()
+                    if errors:
+                        raise errors[0]
+                except BaseException as exc:
+                    with open(os.path.join(shm.shm_dir(), failed_name(me)), "w") as fh:   # the peers stop polling and raise
+                        fh.write(f"{type(exc).__name__}: {exc}")
+                    cleanup.append(os.path.join(shm.shm_dir(), failed_name(me)))
+                    raise
+                finally:
+                    if lifted:
+                        set_host_threads(0)
+            if sharing:
+                t0 = tick()
+                for pc in pieces:
+                    b = builder_of[pc]
+                    if b == me:
+                        continue
+                    if peers[b]["n_wg"] != n_wg:
+                        raise RuntimeError(f"process {b} cuts layouts for {peers[b]['n_wg']} workgroups, this device wants {n_wg}")
+                    t1 = tick()
+                    shm.wait_for(seg_name(b, pc), wait_s, failed_name(b))
+                    t2 = tick()
+                    X.attach_layout(seg_path(b, pc))                 # mapped, not copied
+                    t3 = tick()
+                    X.preload_layout(pc[1], pc[0], n_wg, device)     # upload it now, beside the wait for the next piece
+                    if detail is not None:
+                        detail[f"wait_side{pc[1]}_s"] = t2 - t1
+                        detail[f"attach_side{pc[1]}_s"] = t3 - t2
+                        detail[f"preload_side{pc[1]}_s"] = tick() - t3
+                if detail is not None:
+                    detail["wait_and_attach_s"] = tick() - t0
+            if not sharing and int(concurrent) > 1 and not X.is_shell:
+                # nobody to share with, but several units in flight: cut (and upload) the sweep's layouts once, here, instead of
+                # letting the first units' threads cut the same pair side by side
+                for pc in pieces:
+                    X.preload_layout(pc[1], pc[0], n_wg, device)
+        except BaseException as exc:                      # noqa: BLE001 -- carried through the process group below
+            layout_error = exc
     if warm is not None:
         warm.join()
+    # A layout phase that failed on ONE process (a builder's cut, a peer's wait or n_wg check) must not leave the others in
+    # the collectives below until the backend's timeout: the failure travels as a flag every process reaches, the files
+    # this process put into the node's memory file system go (finished segments, a half-written .part, the failure note
+    # the node's pollers have read by now), and every process raises.
+    failed_here = None if layout_error is None else f"{type(layout_error).__name__}: {layout_error}"
+    if _any_failed(failed_here is not None, world, group, device):
+        notes = [failed_here]
+        if world > 1:
+            notes = [None] * world
+            dist.all_gather_object(notes, failed_here, group=group)
+        _remove_files(cleanup)
+        if layout_error is not None:
+            raise layout_error
+        who = next(p for p in range(world) if notes[p] is not None)
+        raise ShardedRunError(f"the layout phase failed on process {who}: {notes[who]}")
     t_layout = time.perf_counter()
 
     # ---- the result segment of this node: [ew | eh | sdw | sdh] of every unit, written by the unit's owner
     offsets, total = _unit_offsets(tasks, n, m)
     rseg = None
-    if world > 1 and len(my_node) > 1:
+    if world > 1:
+        # EVERY process takes part in these collectives, whatever its node looks like (a node with one process, or one taken
+        # apart for lack of room, shares nothing but must not leave the others waiting: nodes {0,1} + {2} used to hang here)
         leader = my_node[0]
-        box = [None] * world
-        if me == leader:
-            rseg = shm.Segment.create(shm.fresh_name("results"), total)
-        dist.all_gather_object(box, rseg.name if me == leader else None, group=group)
-        if me != leader:
-            rseg = shm.Segment.open(box[leader])
-        dist.barrier(group=group)                        # every process of the node has imported the layouts and mapped the results
-        rseg.unlink()                                    # mapped everywhere: the name can go, the memory lives with the mappings
-        for path in cleanup:                             # every peer holds its mapping: the names can go
+        shares = len(my_node) > 1
+        seg_error = None
+        if shares and me == leader:
             try:
-                os.unlink(path)
-            except FileNotFoundError:
-                pass
-        bundle["state_out"] = lambda irun, r: _unit_views(rseg, offsets[tasks.index((irun, int(r)))], n, m, int(r))
+                rseg = shm.Segment.create(shm.fresh_name("results"), total)
+            except BaseException as exc:                 # noqa: BLE001
+                seg_error = f"{type(exc).__name__}: {exc}"
+        box = [None] * world
+        dist.all_gather_object(box, (rseg.name if (shares and me == leader and rseg is not None) else None, seg_error), group=group)
+        if shares and me != leader and box[leader][0] is not None:
+            try:
+                rseg = shm.Segment.open(box[leader][0])
+            except BaseException as exc:                 # noqa: BLE001
+                seg_error = f"{type(exc).__name__}: {exc}"
+        bad = seg_error is not None or any(b[1] is not None for b in box)
+        # (the flag's all-reduce is also the barrier: behind it every process of every node has imported the layouts and
+        # mapped the results)
+        bad = _any_failed(bad, world, group, device)
+        if rseg is not None:
+            rseg.unlink()                                # mapped everywhere: the name can go, the memory lives with the mappings
+        _remove_files(cleanup)                           # every peer holds its mapping: the names can go
+        if bad:
+            first = next((f"process {p}: {b[1]}" for p, b in enumerate(box) if b[1] is not None), seg_error)
+            raise ShardedRunError(f"the result segment could not be set up ({first})")
+        if rseg is not None:
+            bundle["state_out"] = lambda irun, r: _unit_views(rseg, offsets[tasks.index((irun, int(r)))], n, m, int(r))
 
     # A unit that raises (hyper-parameter Newton failure, a VBNMFError, rank > min(nrow, ncol) ...) must not keep this
     # process from the collectives below: the others would wait in them for ever.  The error travels as a flag, every
@@ -441,7 +501,10 @@ class CellPartitionedEngine:
     engine through ``engine``); there is no device-driven loop on that path.
     """
 
-    def __init__(self, X, rank, device=0, group=None, engine=None, native=None):
+    def __init__(self, X, rank, device=0, group=None, engine=None, native=None, block=None):
+        """block = (col_begin, col_end, m_global): X holds ONLY this process's column block (m_local = col_end - col_begin
+        columns) -- a process of a node-shared run ingests its own cells and nothing else; the blocks must be
+        cell_partition(m_global, world).  Default: X is the whole matrix and the engine cuts its block out of it."""
         import torch
         import torch.distributed as dist
         self._torch, self._dist = torch, dist
@@ -450,12 +513,17 @@ class CellPartitionedEngine:
         self.world = dist.get_world_size(group) if inited else 1
         self.me = dist.get_rank(group) if inited else 0
         n, m = X.shape
+        if block is not None:
+            cb, ce, m = int(block[0]), int(block[1]), int(block[2])
+            if (cb, ce) != cell_partition(m, self.world)[self.me] or X.shape[1] != ce - cb:
+                raise ValueError(f"block {block} is not this process's share of {m} cells over {self.world} processes")
         self.n, self.m_global, self.rank = n, m, int(rank)
         self.cols = cell_partition(m, self.world)[self.me]
         self.m = self.cols[1] - self.cols[0]
         injected = engine is not None
         if engine is None:
-            engine = VBEngine(X, rank, device=device, cols=self.cols, m_global=m)
+            engine = (VBEngine(X, rank, device=device, cols=(0, self.m), m_global=m) if block is not None
+                      else VBEngine(X, rank, device=device, cols=self.cols, m_global=m))
         self.engine = engine
         if native is None:
             # one process = no exchange: no communicator is built (a box without librccl can still run it) and the

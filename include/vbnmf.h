@@ -317,7 +317,7 @@ int vbnmf_engine_layout_info(const vbnmf_engine *e, int64_t *nnz, int64_t *slots
 
 /* ---------------------------------------------------------------------------------
  * Stateless form: the reference's call, one X in, one updated `wh` out
- * (src/vbnmf_update.cpp:16-101).  Builds a throw-away engine on device 0; use the
+ * (src/vbnmf_update.cpp:16-101).  Builds a throw-away engine on device 0 (or the device the environment variable VBNMF_DEVICE names); use the
  * engine API in a loop.  Outputs as the returned list's lw, lh, ew (= w), eh (= h),
  * dw, dh, lkh (:92-100).
  * --------------------------------------------------------------------------------- */
@@ -375,7 +375,7 @@ int vbnmf_engine_ml_run(vbnmf_engine *e, int32_t prior, double gamma_a, double g
 int vbnmf_engine_ml_likelihood(vbnmf_engine *e, double *lk);
 int vbnmf_engine_ml_get_state(vbnmf_engine *e, double *w, double *h);
 /* Stateless forms of the same step: nmf_updateR(x, w, h, n, m, r, prior, gamma.a, gamma.b)
- * followed by likelihood(x, w, h) (R/factorize.R:2-27, :40-49); throw-away engine on device 0. */
+ * followed by likelihood(x, w, h) (R/factorize.R:2-27, :40-49); throw-away engine on device 0 (VBNMF_DEVICE overrides). */
 int vbnmf_ml_update_dense(int64_t n, int64_t m, int32_t r, const double *X,
                           const double *w_in, const double *h_in,
                           int32_t prior, double gamma_a, double gamma_b,

@@ -1,4 +1,5 @@
 #!/bin/bash
+export BENCH_NO_TRAFFIC=1      # no nested rocprofv3 runs under a profiler (bench.py: measure_sweep_traffic)
 # env-switch sweeps on the round's final build (same box, run through gpurun): (1) the headline under the sweep's run-time
 # knobs now that the cells are ordered, (2) one C5 partition alone under the number of CUs left free for the comm stream.
 export BENCH_NO_SWEEP=1

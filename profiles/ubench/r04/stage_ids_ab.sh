@@ -1,4 +1,5 @@
 #!/bin/bash
+export BENCH_NO_TRAFFIC=1      # no nested rocprofv3 runs under a profiler (bench.py: measure_sweep_traffic)
 # k_update with the inverse index staged in LDS (default) against the global-read form (VBNMF_NO_STAGE_IDS=1): same box,
 # interleaved, ranks 10 and 20; it/s by bench.py, per-kernel times by rocprofv3 for one repetition.
 export BENCH_NO_SWEEP=1 TMPDIR=/tmp

@@ -1,4 +1,5 @@
 #!/bin/bash
+export BENCH_NO_TRAFFIC=1      # no nested rocprofv3 runs under a profiler (bench.py: measure_sweep_traffic)
 # k_update taken apart by compile-time ablation (-DVBNMF_ABL_NOGATHER / _NOSPECIAL / _NOWRITE; results are garbage, the times
 # are what is read): per-side mean duration by rocprofv3 kernel trace at ranks 10 and 20, same box.
 export TMPDIR=/tmp BENCH_NO_SWEEP=1

@@ -1,4 +1,5 @@
 #!/bin/bash
+export BENCH_NO_TRAFFIC=1      # no nested rocprofv3 runs under a profiler (bench.py: measure_sweep_traffic)
 # per-side k_update times at ranks 10 and 20 (run through gpurun from the repo root)
 export TMPDIR=/tmp BENCH_NO_SWEEP=1
 REPO=$PWD

@@ -1,4 +1,5 @@
 #!/bin/bash
+export BENCH_NO_TRAFFIC=1      # no nested rocprofv3 runs under a profiler (bench.py: measure_sweep_traffic)
 export TMPDIR=/tmp
 R=$PWD
 cd /tmp

@@ -177,3 +177,55 @@ def test_sharded_sweep_across_two_pretend_nodes_uses_tensor_broadcasts(tiny_shm,
             assert np.array_equal(a, b)
         for a, b in zip(dcoeff, serial.dcoeff):
             assert np.array_equal(a, b)
+
+
+def _uneven_worker(rank, world, port, q, mode):
+    sys.path.insert(0, ROOT); sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    # nodes {0, 1} + {2}: processes 0 and 1 share their (pretend) node's memory file system, process 2 sits alone
+    os.environ["VBNMF_NODE_KEY"] = "pretend-node-a" if rank < 2 else "pretend-node-b"
+    if mode == "tiny_shm_on_a" and rank < 2:
+        os.environ["VBNMF_TEST_SHM_FREE"] = "4096"                  # ... and node a's /dev/shm is (said to be) full: it is taken apart
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fake_engine import NumpyPhaseEngine
+        from ccfindr_amd import parallel
+        X = _data()
+        tm = {}
+        res = parallel.vb_factorize_sharded(X, ranks=[2, 3, 4, 5], nrun=1, Itmax=12, seed=11, timings=tm,
+                                            engine_factory=lambda M, rk: NumpyPhaseEngine(X, rk))
+        q.put((rank, res.ranks, res.measure, res.nsteps, [np.asarray(b).copy() for b in res.basis],
+               [np.asarray(b).copy() for b in res.dcoeff], tm))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["uneven", "tiny_shm_on_a"])
+def test_sharded_sweep_on_uneven_nodes_every_process_reaches_every_collective(mode):
+    """World 3 with nodes {0, 1} + {2}: the result-segment setup used to call all_gather_object and barrier
+    only on processes whose node has more than one member, so process 2 went on to the records' all-reduce while 0 and 1
+    sat in the gather.  Also with node a short of /dev/shm only (it alone is taken apart).  The result is the serial one,
+    bit for bit, on every process."""
+    sys.path.insert(0, HERE)
+    from fake_engine import NumpyPhaseEngine
+    import ccfindr_amd as C
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33800 + (os.getpid() % 2000) + (7 if mode == "uneven" else 0)
+    procs = [ctx.Process(target=_uneven_worker, args=(k, 3, port, q, mode)) for k in range(3)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=240) for _ in procs], key=lambda o: o[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    X = _data()
+    serial = C.vb_factorize(X, ranks=[2, 3, 4, 5], nrun=1, verbose=0, Itmax=12, seed=11,
+                            engine_factory=lambda M, rk: NumpyPhaseEngine(X, rk))
+    for rank, ranks, measure, nsteps, basis, dcoeff, tm in outs:
+        assert tm["node_processes"] == (1 if (mode == "tiny_shm_on_a" or rank == 2) else 2)
+        assert ranks == serial.ranks and nsteps == serial.nsteps and measure == serial.measure
+        for a, b in zip(basis, serial.basis):
+            assert np.array_equal(a, b)
+        for a, b in zip(dcoeff, serial.dcoeff):
+            assert np.array_equal(a, b)

@@ -66,6 +66,13 @@ def check_all(device):
     away = np.abs(ref) > 0.1                                       # away from the zeros the relative form holds as well
     rel = np.abs(got - ref)[away] / np.abs(ref[away])
     assert np.max(rel) < 1e-13, np.max(rel)
+    # huge arguments (D(x) = x (x+1) ... (x+9) of the upward shift overflows past ~6e30: the routine leaves the shift out
+    # from 1e25 on): finite and exact to rounding up to the end of the fp64 range
+    big = np.array([9.9e24, 1.1e25, 1e28, 7e30, 1e40, 1e100, 1e300])
+    for kind, fn in ((1, mpmath.digamma), (2, mpmath.loggamma)):
+        got_b = evaluate(kind, big, device)
+        ref_b = np.array([float(fn(mpmath.mpf(float(x)))) for x in big])
+        assert np.all(np.isfinite(got_b)) and np.max(np.abs(got_b / ref_b - 1)) < 4e-16, (kind, got_b, ref_b)
     # reciprocal
     got = evaluate(3, xs, device)
     assert np.max(np.abs(got * xs - 1)) < 4e-16
