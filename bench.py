@@ -69,8 +69,11 @@ FP64_PEAK_TFLOPS = 78.6      # MI355X fp64 vector peak (same guide); the sweep's
 HYPER = {"aw": 1.0, "bw": 1.0, "ah": 1.0, "bh": 1.0}
 
 
-def make_workload(small: bool):
+def make_workload(small: bool, world: int = 1, local_rank: int = 0):
     from ccfindr_amd import synth
+    if world > 1:                                    # one generation per node (node_shared_matrix)
+        name, r = (("C3-small 2k x 5k sparse, rank 10", 10) if small else ("C3 20k x 50k CSR-sparse (~5% nnz), rank 10", 10))
+        return name, node_shared_matrix("c3s" if small else "c3", lambda: make_workload(small)[1], world, local_rank), r
     if small:
         n, m, r, k = 2000, 5000, 10, 5
         depth = None
@@ -84,6 +87,71 @@ def make_workload(small: bool):
         name = "C3 20k x 50k CSR-sparse (~5% nnz), rank 10"
     X = synth.fill_empty(X, seed=3)
     return name, X, r
+
+
+def node_rank():
+    """This process's rank INSIDE its node (torch.distributed.run's LOCAL_RANK) -- not the device index, which a rehearsal
+    may force to 0 for every rank (BENCH_ONE_DEVICE)."""
+    try:
+        return int(os.environ.get("LOCAL_RANK", "0"))
+    except ValueError:
+        return 0
+
+
+def node_shared_matrix(tag, make, world, local_rank=None):
+    """The synthetic matrix `make()` builds, ONCE PER NODE: under `--gpus N` the node's local rank 0 generates it (22 s for
+    the headline matrix, two minutes for C5 on one core -- N ranks used to repeat that side by side) and puts its compressed
+    columns into the node's memory file system; the other ranks map them.  Every rank gets a scipy CSC matrix over the
+    same bytes.  BENCH_GEN_COUNTER names a file that receives one line per generation (tests/test_bench_launch.py)."""
+    import scipy.sparse as sp
+
+    def generate():
+        X = make().tocsc()
+        X.sort_indices()
+        counter = os.environ.get("BENCH_GEN_COUNTER")
+        if counter:
+            with open(counter, "a") as fh:
+                fh.write(f"{tag} pid {os.getpid()}\n")
+        return X
+
+    if world <= 1:
+        return generate()
+    local_rank = node_rank()
+    import torch.distributed as dist
+    from ccfindr_amd import node as shm
+    box = [f"{os.getpid()}_{time.time_ns()}" if dist.get_rank() == 0 else None]
+    dist.broadcast_object_list(box, src=0)                       # one name for this run on every node
+    base = os.path.join(shm.shm_dir(), f"vbnmf_bench_{tag}_{box[0]}")
+    names = {k: f"{base}_{k}.npy" for k in ("indptr", "indices", "data", "shape")}
+    X = None
+    if local_rank == 0:
+        X = generate()
+        idt = np.int32 if X.nnz < 2 ** 31 - 1 else np.int64
+        np.save(names["indptr"], X.indptr.astype(idt, copy=False))
+        np.save(names["indices"], X.indices.astype(idt, copy=False))
+        np.save(names["data"], np.asarray(X.data, dtype=np.float64))
+        np.save(names["shape"], np.asarray(X.shape, dtype=np.int64))
+    dist.barrier()
+    if local_rank != 0:
+        shape = tuple(int(v) for v in np.load(names["shape"]))
+        X = sp.csc_matrix((np.load(names["data"], mmap_mode="r"), np.load(names["indices"], mmap_mode="r"),
+                           np.load(names["indptr"], mmap_mode="r")), shape=shape, copy=False)
+    dist.barrier()                                               # mapped everywhere: the names can go
+    if local_rank == 0:
+        for path in names.values():
+            try:
+                os.unlink(path)
+            except FileNotFoundError:
+                pass
+    return X
+
+
+def local_world():
+    """Ranks of this node (torch.distributed.run exports it): the host threads of ingestion and layout cuts are shared."""
+    try:
+        return max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+    except ValueError:
+        return 1
 
 
 def algorithmic_bytes(n, m, r, nnz):
@@ -168,9 +236,17 @@ def cells_partitioned_sample(world, rank, local_rank, barrier, steps, small=Fals
     import ccfindr_amd as C
     from ccfindr_amd import synth
     from ccfindr_amd.parallel import CellPartitionedEngine
-    X, n, m, r = make_c5(small)
-    M = C.CountMatrix(X)
-    eng = CellPartitionedEngine(M, r, device=local_rank)
+    if small:
+        n, m, r = 3000, 16000, 20
+    else:
+        n, m, r = 30000, 200000, 20
+    X = node_shared_matrix("c5s" if small else "c5", lambda: make_c5(small)[0], world, local_rank)
+    assert X.shape == (n, m)
+    # every rank ingests ITS column block and nothing else (the engine of a partition never looks at other cells)
+    from ccfindr_amd.parallel import cell_partition
+    cb0, ce0 = cell_partition(m, world)[rank]
+    M = C.CountMatrix(X[:, cb0:ce0] if world > 1 else X)
+    eng = CellPartitionedEngine(M, r, device=local_rank, block=(cb0, ce0, m) if world > 1 else None)
     wh = synth.random_state(n, m, r, HYPER, seed=1005)
     eng.set_state(wh["lw"], wh["lh"], wh["eh"])
     device_loop = eng.native or world == 1
@@ -216,7 +292,7 @@ def cells_partitioned_sample(world, rank, local_rank, barrier, steps, small=Fals
         torch.cuda.synchronize()
         ar_ms = float(np.median([a.elapsed_time(b) for a, b in pairs[2:]]))
     cb, ce = eng.cols
-    S = X.tocsc()
+    S = X
     nnz_local = int(S.indptr[ce] - S.indptr[cb])
     m_local = ce - cb
     bytes_gpu = 12 * nnz_local + 4 * (n + 1) + 48 * (n * r + r * m_local)       # SURVEY section 8(d), this GPU's share
@@ -421,7 +497,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    name, X, r = make_workload(args.small)
+    if world > 1 and local_world() > 1 and not os.environ.get("VBNMF_HOST_THREADS"):
+        # the node's ranks ingest and cut side by side: each takes its share of the host's cores (default: up to 32 each)
+        from ccfindr_amd.engine import set_host_threads
+        set_host_threads(max(1, len(os.sched_getaffinity(0)) // local_world()))
+    name, X, r = make_workload(args.small, world, local_rank)
     if args.rank > 0 and args.rank != r:
         r = args.rank
         name = name.replace("rank 10", f"rank {r} (diagnostic, not the headline rank)")

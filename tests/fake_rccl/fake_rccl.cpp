@@ -12,9 +12,20 @@
 // so kernels queued behind it on the stream see the reduced data, kernels on other streams run beside it, and a rank
 // whose peer never arrives stays on hipErrorNotReady -- exactly what the library's timeouts must handle.  The wait inside
 // the host function gives up after FAKE_RCCL_TIMEOUT_S (default 60) so that a process can still exit.
+//
+// FAKE_RCCL_KERNEL=1 (round 5): the collective is carried by KERNELS, like the real one -- a host function occupies no CU
+// and no LDS, so it could not show whether an all-reduce RUNS beside the persistent cell-side sweep on the CUs
+// VBNMF_COMM_CUS leaves free.  Every rank owns an exchange buffer in device memory, opened by its peers through HIP IPC
+// (hipIpcGetMemHandle / hipIpcOpenMemHandle; the handles travel through the shared segment): [flags | slot 0 | slot 1].
+//   k_copy_in  (a few blocks)            waits until every peer has finished reading this parity's slot two collectives ago,
+//                                        copies `send` into the rank's slot, publishes ready = k + 1 (system-scope atomic)
+//   k_reduce   (FAKE_RCCL_BLOCKS x 512   spins (bounded) until every rank's ready >= k + 1, sums the peers' slots IN RANK
+//               threads, 4 KB of LDS)    ORDER straight into `recv`, publishes done = k + 1
+// -- RCCL's launch shape (tens of blocks, a few KB of LDS each, spinning on peers' flags), the same stream order.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -38,10 +49,103 @@ struct Header {
     std::atomic<uint32_t> left;                          // ranks that destroyed their communicator
     std::atomic<uint64_t> ready[kMaxRanks];              // ops whose input slot is complete, per rank
     std::atomic<uint64_t> read[kMaxRanks];               // ops whose inputs this rank has finished reading
+    std::atomic<uint32_t> ipc_ready[kMaxRanks];          // kernel-carried form: this rank's IPC handle is in place
+    std::atomic<uint32_t> ipc_opened;                    // ... ranks that have opened every peer's buffer
+    hipIpcMemHandle_t ipc[kMaxRanks];
 };
 static_assert(sizeof(Header) <= kHeaderBytes, "header too large");
 
+// ---- kernel-carried form -----------------------------------------------------------------------------------------
+constexpr size_t kDevSlotBytes = (size_t)8 << 20;        // per parity
+constexpr size_t kDevHeaderBytes = 4096;
+struct DevHeader {                                       // at the start of a rank's exchange buffer; written by its owner only
+    unsigned long long ready;                            // collectives whose input slot is complete
+    unsigned long long done;                             // collectives whose inputs this rank has finished reading
+    unsigned int arrive_in, arrive_red;                  // block counters of the two kernels (owner-local)
+    unsigned int broken;
+};
+struct PeerTable { char *buf[kMaxRanks]; };
+
+__device__ inline const DevHeader *hdr(const PeerTable &P, int r) { return reinterpret_cast<const DevHeader *>(P.buf[r]); }
+__device__ inline double *dslot(const PeerTable &P, int r, unsigned long long k)
+{
+    return reinterpret_cast<double *>(P.buf[r] + kDevHeaderBytes + (size_t)(k & 1) * kDevSlotBytes);
+}
+// thread 0 of the block: wait until every rank's flag (ready: which = 0, done: which = 1) has reached `want`; bounded
+__device__ inline bool wait_flags(const PeerTable &P, int nranks, int which, unsigned long long want, unsigned long long ticks)
+{
+    const unsigned long long t0 = wall_clock64();
+    for (;;) {
+        bool ok = true;
+        for (int r = 0; r < nranks; r++) {
+            const unsigned long long *f = which ? &hdr(P, r)->done : &hdr(P, r)->ready;
+            ok = ok && __hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= want;
+        }
+        if (ok) return true;
+        if (wall_clock64() - t0 > ticks) return false;
+        __builtin_amdgcn_s_sleep(32);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_copy_in(PeerTable P, int nranks, int rank, const double *__restrict__ send, size_t count,
+                                                 unsigned long long k, unsigned long long ticks)
+{
+    __shared__ int ok;
+    DevHeader *me = reinterpret_cast<DevHeader *>(P.buf[rank]);
+    if (threadIdx.x == 0) ok = (k < 2) ? 1 : (wait_flags(P, nranks, 1, k - 1, ticks) ? 1 : 0);     // this parity's slot is free again
+    __syncthreads();
+    if (ok) {
+        double *dst = dslot(P, rank, k);
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) dst[i] = send[i];
+    }
+    __threadfence_system();                              // the slot's stores are out before the flag
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (!ok) me->broken = 1;
+        if (atomicAdd(&me->arrive_in, 1u) == gridDim.x - 1) {                // the last block publishes
+            me->arrive_in = 0;
+            __hip_atomic_store(&me->ready, k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+__global__ __launch_bounds__(512) void k_reduce(PeerTable P, int nranks, int rank, int root, double *__restrict__ recv, size_t count,
+                                                unsigned long long k, unsigned long long ticks)
+{
+    __shared__ double lds_pad[512];                      // 4 KB: an RCCL-like LDS footprint (keeps the block off CUs whose LDS is full)
+    __shared__ int ok;
+    DevHeader *me = reinterpret_cast<DevHeader *>(P.buf[rank]);
+    if (threadIdx.x == 0) ok = wait_flags(P, nranks, 0, k + 1, ticks) ? 1 : 0;
+    lds_pad[threadIdx.x] = (double)threadIdx.x;
+    __syncthreads();
+    if (ok) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");    // the peers' slots were written by other processes' kernels
+        for (size_t i = (size_t)blockIdx.x * 512 + threadIdx.x; i < count; i += (size_t)gridDim.x * 512) {
+            double s;
+            if (root >= 0) s = dslot(P, root, k)[i];
+            else {
+                s = dslot(P, 0, k)[i];
+                for (int r = 1; r < nranks; r++) s += dslot(P, r, k)[i];            // rank order: every rank forms the same bits
+            }
+            recv[i] = s;
+        }
+    }
+    if (lds_pad[(threadIdx.x * 7) & 511] < 0.0) recv[0] = 0.0;                      // (never true: keeps the LDS array alive)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (!ok) me->broken = 1;
+        if (atomicAdd(&me->arrive_red, 1u) == gridDim.x - 1) {
+            me->arrive_red = 0;
+            __hip_atomic_store(&me->done, k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 struct Comm {
+    bool kernel_mode = false;
+    char *devbuf = nullptr;                              // this rank's exchange buffer (device memory, IPC-shared)
+    PeerTable peers{};
+    int red_blocks = 24;
     int nranks = 0, rank = 0;
     std::string path;
     char *base = nullptr;
@@ -110,6 +214,15 @@ ncclResult_t collective(const void *send, void *recv, size_t count, ncclDataType
     if (!c || dt != ncclDouble) return ncclInvalidArgument;
     if (count * sizeof(double) > kSlotBytes) return ncclInvalidArgument;
     if (c->broken.load()) return ncclSystemError;
+    if (c->kernel_mode) {
+        if (count * sizeof(double) > kDevSlotBytes) return ncclInvalidArgument;
+        const unsigned long long k = c->ops++;
+        const unsigned long long ticks = (unsigned long long)(c->timeout_s * 1e8);          // wall_clock64: 100 MHz
+        const int nb_in = (int)std::min<size_t>(8, (count + 255) / 256 ? (count + 255) / 256 : 1);
+        hipLaunchKernelGGL(k_copy_in, dim3(nb_in), dim3(256), 0, stream, c->peers, c->nranks, c->rank, static_cast<const double *>(send), count, k, ticks);
+        hipLaunchKernelGGL(k_reduce, dim3(c->red_blocks), dim3(512), 0, stream, c->peers, c->nranks, c->rank, root, static_cast<double *>(recv), count, k, ticks);
+        return hipGetLastError() == hipSuccess ? ncclSuccess : ncclUnhandledCudaError;
+    }
     Op *op = new Op{c, c->ops++, count, root};
     if (hipMemcpyAsync(slot(c, c->rank), send, count * sizeof(double), hipMemcpyDeviceToHost, stream) != hipSuccess) return ncclUnhandledCudaError;
     if (hipLaunchHostFunc(stream, host_reduce, op) != hipSuccess) return ncclUnhandledCudaError;
@@ -163,6 +276,32 @@ ncclResult_t ncclCommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId id, int
         std::this_thread::sleep_for(std::chrono::milliseconds(1));
     }
     if (rank == 0) unlink(c->path.c_str());                            // every rank holds its mapping: the name can go
+    const char *km = getenv("FAKE_RCCL_KERNEL");
+    if (km && km[0] == '1') {
+        // the exchange buffers: allocate, publish the IPC handle, open every peer's
+        if (const char *b = getenv("FAKE_RCCL_BLOCKS")) { const int v = atoi(b); if (v >= 1 && v <= 256) c->red_blocks = v; }
+        const size_t devbytes = kDevHeaderBytes + 2 * kDevSlotBytes;
+        bool ok = hipMalloc(reinterpret_cast<void **>(&c->devbuf), devbytes) == hipSuccess && hipMemset(c->devbuf, 0, devbytes) == hipSuccess &&
+                  hipDeviceSynchronize() == hipSuccess && hipIpcGetMemHandle(&c->h->ipc[rank], c->devbuf) == hipSuccess;
+        if (ok) c->h->ipc_ready[rank].store(1, std::memory_order_release);
+        const auto t1 = std::chrono::steady_clock::now();
+        for (int r = 0; ok && r < nranks; r++) {
+            while (!c->h->ipc_ready[r].load(std::memory_order_acquire)) {
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count() > c->timeout_s) { ok = false; break; }
+                std::this_thread::sleep_for(std::chrono::milliseconds(1));
+            }
+            if (!ok) break;
+            if (r == rank) c->peers.buf[r] = c->devbuf;
+            else ok = hipIpcOpenMemHandle(reinterpret_cast<void **>(&c->peers.buf[r]), c->h->ipc[r], hipIpcMemLazyEnablePeerAccess) == hipSuccess;
+        }
+        if (!ok) {
+            fprintf(stderr, "[fake_rccl] rank %d: the IPC exchange buffers could not be set up (%s)\n", rank, hipGetErrorString(hipGetLastError()));
+            return ncclUnhandledCudaError;
+        }
+        c->h->ipc_opened.fetch_add(1);
+        while (c->h->ipc_opened.load() < (uint32_t)nranks) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        c->kernel_mode = true;
+    }
     *comm = reinterpret_cast<ncclComm_t>(c);
     return ncclSuccess;
 }
@@ -173,6 +312,15 @@ ncclResult_t ncclCommDestroy(ncclComm_t comm)
     if (!c) return ncclSuccess;
     c->broken.store(1);                                                // a host function still waiting leaves at once
     c->h->left.fetch_add(1);
+    if (c->kernel_mode) {
+        (void)hipDeviceSynchronize();
+        for (int r = 0; r < c->nranks; r++) if (r != c->rank && c->peers.buf[r]) (void)hipIpcCloseMemHandle(c->peers.buf[r]);
+        // (the owner's buffer stays allocated until every peer has left: a peer's kernel may still poll its flags)
+        const auto t0 = std::chrono::steady_clock::now();
+        while (c->h->left.load() < (uint32_t)c->nranks && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 5.0)
+            std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        (void)hipFree(c->devbuf);
+    }
     if (c->pinned) (void)hipHostUnregister(slot(c, c->rank));
     (void)hipHostFree(c->result);
     munmap(c->base, c->bytes);

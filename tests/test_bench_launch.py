@@ -40,11 +40,21 @@ def test_bare_launch_two_ranks_on_one_gpu_prints_one_json_line():
     fake = os.path.join(ROOT, "tests", "fake_rccl", "_build", "libfake_rccl.so")
     assert os.path.exists(fake)
     # two ranks on the ONE test GPU: gloo for torch.distributed, the librccl stand-in for the library's own collective
-    env = dict(os.environ, BENCH_BACKEND="gloo", BENCH_ONE_DEVICE="1", VBNMF_RCCL_LIB=fake)
+    import tempfile
+    import time
+    counter = tempfile.NamedTemporaryFile(prefix="bench_gen_", suffix=".txt", delete=False).name
+    env = dict(os.environ, BENCH_BACKEND="gloo", BENCH_ONE_DEVICE="1", VBNMF_RCCL_LIB=fake, BENCH_GEN_COUNTER=counter)
     env.pop("WORLD_SIZE", None)
+    t0 = time.perf_counter()
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--small", "--steps", "5", "--warmup", "2",
                         "--no-cpu", "--no-ml"], env=env, capture_output=True, text=True, timeout=900)
+    print(f"two-rank rehearsal: {time.perf_counter() - t0:.1f} s wall")
     assert p.returncode == 0, p.stderr[-2000:]
+    # ONE generation of each synthetic matrix per node, whatever the number of ranks: the node's local
+    # rank 0 generates, the others map its arrays
+    gens = sorted(ln.split()[0] for ln in open(counter).read().splitlines())
+    os.unlink(counter)
+    assert gens == ["c3s", "c5s"], gens
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
     out = json.loads(lines[0])

@@ -37,11 +37,15 @@ def _problem(kind):
     return X, n, m, r, hy, kw, synth.random_state(n, m, r, hy, seed=5)
 
 
-def _worker(rank, world, port, kind, q):
+def _worker(rank, world, port, kind, carrier, q):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     os.environ["VBNMF_RCCL_LIB"] = FAKE
     os.environ["FAKE_RCCL_TIMEOUT_S"] = "20"
+    # carrier "kernel": the stand-in's collectives are KERNELS over IPC-mapped peer buffers, RCCL's launch shape (tens of
+    # blocks x 512 threads, a few KB of LDS, spinning on the peers' flags); "host": a host function on the stream
+    os.environ["FAKE_RCCL_KERNEL"] = "1" if carrier == "kernel" else "0"
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -75,11 +79,12 @@ def _spawn(target, args, world=2, timeout=300):
     return procs, q
 
 
+@pytest.mark.parametrize("carrier", ["host", "kernel"])
 @pytest.mark.parametrize("kind", ["itmax", "converge"])
-def test_two_ranks_of_the_rccl_protocol_equal_the_single_engine(kind):
+def test_two_ranks_of_the_rccl_protocol_equal_the_single_engine(kind, carrier):
     import ccfindr_amd as C
     assert os.path.exists(FAKE), "tests/fake_rccl is not built (make, or __graft_entry__.build())"
-    procs, q = _spawn(_worker, (kind,))
+    procs, q = _spawn(_worker, (kind, carrier))
     outs = sorted([q.get(timeout=300) for _ in procs], key=lambda o: o[0])
     for p in procs:
         p.join(timeout=60)
