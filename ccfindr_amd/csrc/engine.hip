@@ -195,9 +195,18 @@ int sweep_workgroups(int device, bool partitioned, int &n_wg)
     const char *forced = getenv("VBNMF_NWG");
     if (forced) { int v = atoi(forced); if (v > 0) n_wg = v; }
     if (partitioned && !forced) {
-        // A partition's sweep leaves a few CUs free: its workgroups own all 160 KB of a CU's LDS, so the all-reduce
-        // kernels that should run BESIDE the cell-side sweep could not start on a chip filled by it.
-        int spare = 8;
+        // A partition's sweep leaves CUs free: its workgroups own all 160 KB of a CU's LDS, so the all-reduce kernels that
+        // should run BESIDE the cell-side sweep could not start on a chip filled by it.  How many: ONE PER SHADER ENGINE
+        // (8 XCDs x 4 engines = 32).  Measured in round 5 with the collective carried by kernels of RCCL's launch shape
+        // (tests/fake_rccl, FAKE_RCCL_KERNEL=1: 24 or 64 blocks x 512 threads, 4 KB of LDS; profiles/r05_c5_overlap.txt, one C5
+        // partition): with 8 or 16 CUs free the collective's first kernel still ENDS WITH the sweep (155-166 us instead of
+        // 25 alone) -- a queue's workgroups are dealt to the shader engines in turn, and the first one dealt to an engine
+        // whose CUs are all full stalls the whole queue behind it -- with 32 free it runs inside the sweep (37 + 40 us,
+        // done 170 us before the sweep ends).  Price: the two sweeps on 224 instead of 248 workgroups, +21 us per step
+        // (0.427 against 0.411 ms with no reserve and this one-rank collective trailing the sweep): the reserve pays as soon
+        // as the real all-reduce over xGMI takes more than ~25 us alone (4.8 MB: >= 55 us by SURVEY.md section 5's ring estimate).
+        // VBNMF_COMM_CUS overrides (0: no reserve).
+        int spare = 32;
         if (const char *sv = getenv("VBNMF_COMM_CUS")) spare = atoi(sv);
         if (spare >= 0 && n_wg - spare >= 8) n_wg -= spare;
     }
@@ -1028,8 +1037,14 @@ int vbnmf_engine_create_geom(const vbnmf_matrix *X, int64_t cb, int64_t ce, int6
         std::shared_ptr<const Layout> shared2[2];
         Layout own2[2];
         const Layout *Ls[2] = {nullptr, nullptr};
-        for (int side = 0; side < 2 && !rc; side++) {
-            int64_t nmaj = side == 0 ? e->n : e->m, nmin = side == 0 ? e->m : e->n;
+        // The two sides are cut (or taken from the matrix's cache) and uploaded SIDE BY SIDE: the cell side on a second host
+        // thread, the gene side here.  Each cut is memory-bound well before it uses all host threads, and a side's upload
+        // (200 MB of pageable memory at the headline size) runs beside the other side's cut.  Engine creation at the headline
+        // size: 0.41 -> 0.3 s on the GPU box (profiles/r05_setup_times.txt).  VBNMF_SERIAL_SIDES=1: one after the other.
+        if (cb == 0 && ce == X->M.m && !X->M.shell) (void)X->M.cell_order();          // (both sides start from it: formed once, here)
+        auto do_side = [&](int side) -> int {
+            int src = VBNMF_OK;
+            const int64_t nmaj = side == 0 ? e->n : e->m, nmin = side == 0 ? e->m : e->n;
             // The geometry is that of the matrix's rank CLASS (vbnmf_matrix_plan_ranks; without a plan the class is this
             // rank's own): the ranks of a sweep share one pair of layouts, cut for the widest rows among them.
             const int Rc = geometry_rank ? padded_rank(geometry_rank) : std::max(e->R, plan_class(X, e->R));
@@ -1039,16 +1054,37 @@ int vbnmf_engine_create_geom(const vbnmf_matrix *X, int64_t cb, int64_t ce, int6
             Layout &own = own2[side];
             const Layout *L = &own;
             if (cb == 0 && ce == X->M.m) {                   // whole matrix: the layout may already exist (another rank, a restart)
-                shared = shared_layout(X, side, lp, rc);
+                shared = shared_layout(X, side, lp, src);
                 L = shared.get();
             } else {
-                rc = build_layout(X->M, cb, ce, side, lp, &part_order, own);
+                src = build_layout(X->M, cb, ce, side, lp, &part_order, own);
             }
-            if (!rc) rc = upload_side(*L, e->R, device, shared ? X : nullptr, side == 0 ? e->A : e->B);
-            if (!rc && side == 0) { e->nnz = L->nnz; e->cell_perm = L->cell_perm; }
-            if (!rc && side == 1 && L->cell_perm != e->cell_perm) rc = fail(VBNMF_ERR_STATE, "the two sides' layouts disagree on the order of the cells");
+            if (!src) src = upload_side(*L, e->R, device, shared ? X : nullptr, side == 0 ? e->A : e->B);
             Ls[side] = L;
+            return src;
+        };
+        static const bool serial_sides = [] { const char *v = getenv("VBNMF_SERIAL_SIDES"); return v && v[0] == '1'; }();
+        int rc1 = VBNMF_OK;
+        std::string msg1;
+        bool oom1 = false;
+        if (serial_sides) {
+            rc = do_side(0);
+            if (!rc) rc = do_side(1);
+        } else {
+            std::thread cell_side([&] {
+                try {
+                    if (hipSetDevice(device) != hipSuccess) { rc1 = VBNMF_ERR_HIP; msg1 = "hipSetDevice failed on the layout thread"; return; }
+                    rc1 = do_side(1);
+                    if (rc1) msg1 = last_error_cstr();               // (error messages are per host thread)
+                } catch (const std::bad_alloc &) { oom1 = true; }
+            });
+            try { rc = do_side(0); } catch (...) { cell_side.join(); throw; }
+            cell_side.join();
+            if (oom1) throw std::bad_alloc();
+            if (!rc && rc1) rc = fail(rc1, "%s", msg1.c_str());
         }
+        if (!rc) { e->nnz = Ls[0]->nnz; e->cell_perm = Ls[0]->cell_perm; }
+        if (!rc && Ls[1]->cell_perm != e->cell_perm) rc = fail(VBNMF_ERR_STATE, "the two sides' layouts disagree on the order of the cells");
         if (!rc) {
             // One launch for both posterior updates (k_update2): unpartitioned engines whose blocks' work fits the kernel's
             // table; VBNMF_NO_UPDATE_PAIR=1 keeps the two launches (A/B switch, and the form the pair is held to in

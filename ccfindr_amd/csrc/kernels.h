@@ -103,6 +103,9 @@ __device__ __forceinline__ void pin_offsets(Group4 &g)
 #ifndef VBNMF_STREAM_NT
 #define VBNMF_STREAM_NT 1
 #endif
+#ifndef VBNMF_PREFETCH2
+#define VBNMF_PREFETCH2 0
+#endif
 __device__ __forceinline__ uint4 ld_stream(const uint4 *p)
 {
 #if VBNMF_STREAM_NT
@@ -111,6 +114,42 @@ __device__ __forceinline__ uint4 ld_stream(const uint4 *p)
     return make_uint4(v.x, v.y, v.z, v.w);
 #else
     return *p;
+#endif
+}
+// The per-task partial rows (75 MB per sweep at the headline size) are written once and gathered back by the update kernels.
+// VBNMF_PART_NT=1 stores them with the non-temporal policy (experiment: profiles/r05_part_nt_ab.txt).
+#ifndef VBNMF_PART_NT
+#define VBNMF_PART_NT 0
+#endif
+__device__ __forceinline__ void st_part(double2 *p, double2 v)
+{
+#if VBNMF_PART_NT
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    f64x2 w; w.x = v.x; w.y = v.y;
+    __builtin_nontemporal_store(w, reinterpret_cast<f64x2 *>(p));
+#else
+    *p = v;
+#endif
+}
+// The update kernels gather every partial row once and write the means / variances (e, d) that nothing on the device reads
+// again before the next update: VBNMF_UPD_NT=1 gives both the non-temporal policy (experiment: profiles/r05_upd_nt_ab.txt).
+#ifndef VBNMF_UPD_NT
+#define VBNMF_UPD_NT 0
+#endif
+__device__ __forceinline__ double ld_part(const double *p)
+{
+#if VBNMF_UPD_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void st_once(double *p, double v)
+{
+#if VBNMF_UPD_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
 #endif
 }
 __device__ __forceinline__ double2 ld_stream(const double2 *p)
@@ -509,6 +548,12 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
                 double2 g1[R / 2];
                 const uint4 *E = reinterpret_cast<const uint4 *>(S.packed + off) + tlane;
                 Group4 a = unpack4<R>(ld_stream(E), share), b = unpack4<R>(ld_stream(E + (size_t)min(1, ng - 1) * 64), share);
+#if VBNMF_PREFETCH2
+                // the entry stream TWO trips ahead: the groups of trip p + 1 are on their way (ec, ed) when trip p issues the
+                // loads of trip p + 2 -- with the stream read non-temporally every group comes from HBM, 1.5-2 us under load,
+                // about what ONE trip of three interleaved waves takes
+                uint4 ec = ld_stream(E + (size_t)min(2, ng - 1) * 64), ed = ld_stream(E + (size_t)min(3, ng - 1) * 64);
+#endif
                 lds_row<R>(ldsG, a.o0, g0);
                 // FENCE keeps the machine scheduler from sinking a row's LDS reads down to their first
                 // use: the reads of entry j+1 stay in front of the arithmetic of entry j, which hides them.
@@ -517,10 +562,17 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
                 // stored ones (layout: slice_fast), PIN = the matching pin of the next trip's unpacked groups.
                 // MODE: 0 general, 1 the leading ones, 2 the ones-or-twos behind them (gene side only: it defers the logarithm)
 #define VBNMF_ENTRY(MODE, gv, cnt) sweep_entry<R, EV == 3, (MODE) == 1, SP, (MODE) == 2>(T, ldsG, gv, (double)(cnt), LOGTERM); if ((MODE) == 2 && LOGTERM) renorm_product<R>(T); VBNMF_FENCE()
+#if VBNMF_PREFETCH2
+#define VBNMF_TRIP_LOADS const uint4 fc = ld_stream(E + (size_t)min(2 * p + 4, ng - 1) * 64), fd = ld_stream(E + (size_t)min(2 * p + 5, ng - 1) * 64);
+#define VBNMF_TRIP_ROTATE ec = fc; ed = fd;
+#else
+#define VBNMF_TRIP_LOADS const uint4 ec = ld_stream(E + (size_t)min(2 * p + 2, ng - 1) * 64), ed = ld_stream(E + (size_t)min(2 * p + 3, ng - 1) * 64);
+#define VBNMF_TRIP_ROTATE
+#endif
 #define VBNMF_TRIP(MODE, PIN)                                                                     \
                 {                                                                                 \
                     /* the next trip's groups; past the end: the last group again (an odd one is the tail's) */ \
-                    const uint4 ec = ld_stream(E + (size_t)min(2 * p + 2, ng - 1) * 64), ed = ld_stream(E + (size_t)min(2 * p + 3, ng - 1) * 64); \
+                    VBNMF_TRIP_LOADS                                                              \
                     lds_row<R>(ldsG, a.o1, g1); VBNMF_FENCE();                                    \
                     VBNMF_ENTRY(MODE, g0, a.c0);                                                   \
                     lds_row<R>(ldsG, a.o2, g0); VBNMF_FENCE();                                    \
@@ -545,6 +597,7 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
                     if ((MODE) == 1 && LOGTERM) renorm_product<R>(T);                                     \
                     b = unpack4<R>(ed, share);                                                    \
                     PIN(b);                                                                       \
+                    VBNMF_TRIP_ROTATE                                                             \
                 }
                 const int sfast = S.slice_fast[s];
                 const int npf = (EV == 3) ? 0 : min(np, (sfast & 0xFFFF) >> 3);
@@ -566,6 +619,8 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
                 if (LOGTERM && npf2 > 0)                                  // the deferred logarithm of the leading ones and twos
                     T.lsum += fma((double)T.pexp, 6.93147180559945286227e-01, dev_log_tab(T.prod, reinterpret_cast<const LogTabEntry *>(ldsG)));
 #undef VBNMF_TRIP
+#undef VBNMF_TRIP_LOADS
+#undef VBNMF_TRIP_ROTATE
 #undef VBNMF_ENTRY
 #undef VBNMF_FENCE
             } else {
@@ -591,7 +646,7 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
             {
                 double2 *P = reinterpret_cast<double2 *>(S.part + ((size_t)s * 64 + tlane) * RT + hp * R);
 #pragma unroll
-                for (int kk = 0; kk < R / 2; kk++) P[kk] = make_double2(T.acc[2 * kk], T.acc[2 * kk + 1]);
+                for (int kk = 0; kk < R / 2; kk++) st_part(P + kk, make_double2(T.acc[2 * kk], T.acc[2 * kk + 1]));
             }
             if (EV == 1 && M != kIdle) {
                 const double2 *L2 = reinterpret_cast<const double2 *>(S.llF + (size_t)M * RT + hp * R);
@@ -695,7 +750,7 @@ __device__ __forceinline__ double task_sum(const double *__restrict__ part, cons
 #pragma unroll
         for (int u = 0; u < NF; u++) id[u] = inv_task[min(q + u, q1 - 1)];
 #pragma unroll
-        for (int u = 0; u < NF; u++) v[u] = part[(size_t)id[u] * R + k];
+        for (int u = 0; u < NF; u++) v[u] = ld_part(part + (size_t)id[u] * R + k);
 #pragma unroll
         for (int u = 0; u < NF; u++) s += (q + u < q1) ? v[u] : 0.0;
     }
@@ -712,7 +767,7 @@ __device__ __forceinline__ double task_sum_lds(const double *__restrict__ part, 
     for (int q = q0; q < q1; q += NF) {
         double v[NF];
 #pragma unroll
-        for (int u = 0; u < NF; u++) v[u] = part[(size_t)ids[min(q + u, q1 - 1)] * R + k];
+        for (int u = 0; u < NF; u++) v[u] = ld_part(part + (size_t)ids[min(q + u, q1 - 1)] * R + k);
 #pragma unroll
         for (int u = 0; u < NF; u++) s += (q + u < q1) ? v[u] : 0.0;
     }
@@ -1010,7 +1065,7 @@ __global__ __launch_bounds__(kUpdateThreads) void k_update(
 #ifdef VBNMF_ABL_NOWRITE
                 if (ln == 123.456) { l[o] = ln; ll[o] = ln * lg; e[o] = ev; d[o] = dv; }
 #else
-                l[o] = ln; ll[o] = ln * lg; e[o] = ev; d[o] = dv;
+                l[o] = ln; ll[o] = ln * lg; st_once(e + o, ev); st_once(d + o, dv);
 #endif
             } else {
                 l[o] = 0.0; ll[o] = 0.0; e[o] = 0.0; d[o] = 0.0;
@@ -1107,7 +1162,7 @@ __device__ __forceinline__ int posterior_visits(const UpdSide &S, int64_t m0, co
             ve += ev;
             vt += -ab * ev + lga + al * (1.0 - lbe) + lgam;
             vl += lg;
-            S.l[o] = ln; S.ll[o] = ln * lg; S.e[o] = ev; S.d[o] = dv;
+            S.l[o] = ln; S.ll[o] = ln * lg; st_once(S.e + o, ev); st_once(S.d + o, dv);
         } else {
             S.l[o] = 0.0; S.ll[o] = 0.0; S.e[o] = 0.0; S.d[o] = 0.0;
         }

@@ -18,7 +18,7 @@ import shutil
 import sys
 
 STREAMING = ("k_sweep1", "k_sweep", "k_spmm")
-KEYS = ("k_sweep1", "k_sweep", "k_spmm", "k_ml_update", "k_ml_final", "k_ml_control", "k_update", "k_final", "k_prime",
+KEYS = ("k_sweep1", "k_sweep", "k_spmm", "k_ml_update", "k_ml_final", "k_ml_control", "k_update2", "k_update", "k_final", "k_prime",
         "k_control", "k_pack", "k_tail_h", "k_tail_data", "k_tail", "k_group_sum", "k_gamma_init", "k_ctl_init")
 
 

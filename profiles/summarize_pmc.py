@@ -35,7 +35,7 @@ for d in sorted(glob.glob(f"gpurun_out/{tag}_pmc_*")):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(cc)):
         k = short(r["Kernel_Name"])
-        for key in ("k_sweep1", "k_sweep", "k_ml_update", "k_ml_final", "k_update", "k_final", "k_prime", "k_control", "k_pack", "k_tail"):
+        for key in ("k_sweep1", "k_sweep", "k_ml_update", "k_ml_final", "k_update2", "k_update", "k_final", "k_prime", "k_control", "k_pack", "k_tail"):
             if key in r["Kernel_Name"]:
                 k = key
                 break

@@ -87,19 +87,42 @@ __device__ inline bool wait_flags(const PeerTable &P, int nranks, int which, uns
     }
 }
 
-__global__ __launch_bounds__(256) void k_copy_in(PeerTable P, int nranks, int rank, const double *__restrict__ send, size_t count,
-                                                 unsigned long long k, unsigned long long ticks)
+__global__ __launch_bounds__(512) void k_copy_in(PeerTable P, int nranks, int rank, const double *__restrict__ send, size_t count,
+                                                 unsigned long long k, unsigned long long ticks, int vec)
 {
     __shared__ int ok;
+    __shared__ double lds_pad[512];                      // 4 KB, like k_reduce: RCCL's kernels hold LDS, so they only fit CUs whose LDS
+                                                         // the persistent sweep has left free (without it the block lands on ANY CU and is
+                                                         // starved by the sweep's older waves: 160 us instead of 26, r05_c5_overlap.txt)
+    lds_pad[threadIdx.x] = (double)threadIdx.x;
     DevHeader *me = reinterpret_cast<DevHeader *>(P.buf[rank]);
     if (threadIdx.x == 0) ok = (k < 2) ? 1 : (wait_flags(P, nranks, 1, k - 1, ticks) ? 1 : 0);     // this parity's slot is free again
+    // (send / recv / the slots are 16-byte aligned: hipMalloc'd buffers and offsets of whole doubles in pairs -- the library's
+    // reduce buffers start on allocation boundaries; an odd offset would need the scalar path)
     __syncthreads();
     if (ok) {
+        // 16-byte accesses, eight of them in flight per thread (a one-element-per-trip copy is a chain of memory latencies:
+        // 80 us for 4.8 MB alone on the chip, 200 us beside a sweep -- the first version of this kernel)
         double *dst = dslot(P, rank, k);
-        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) dst[i] = send[i];
+        if (!vec) {                                      // (a buffer that does not start on 16 bytes: element by element)
+            for (size_t i = (size_t)blockIdx.x * 512 + threadIdx.x; i < count; i += (size_t)gridDim.x * 512) dst[i] = send[i];
+            count = 0;
+        }
+        const size_t n2 = count / 2, stride = (size_t)gridDim.x * 512;
+        const double2 *s2 = reinterpret_cast<const double2 *>(send);
+        double2 *d2 = reinterpret_cast<double2 *>(dst);
+        for (size_t i = (size_t)blockIdx.x * 512 + threadIdx.x; i < n2; i += 8 * stride) {
+            double2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) if (i + u * stride < n2) v[u] = s2[i + u * stride];
+#pragma unroll
+            for (int u = 0; u < 8; u++) if (i + u * stride < n2) d2[i + u * stride] = v[u];
+        }
+        if ((count & 1) && blockIdx.x == 0 && threadIdx.x == 0) dst[count - 1] = send[count - 1];
     }
     __threadfence_system();                              // the slot's stores are out before the flag
     __syncthreads();
+    if (lds_pad[(threadIdx.x * 7) & 511] < 0.0) me->broken = 2;              // (never true: keeps the LDS array alive)
     if (threadIdx.x == 0) {
         if (!ok) me->broken = 1;
         if (atomicAdd(&me->arrive_in, 1u) == gridDim.x - 1) {                // the last block publishes
@@ -110,7 +133,7 @@ __global__ __launch_bounds__(256) void k_copy_in(PeerTable P, int nranks, int ra
 }
 
 __global__ __launch_bounds__(512) void k_reduce(PeerTable P, int nranks, int rank, int root, double *__restrict__ recv, size_t count,
-                                                unsigned long long k, unsigned long long ticks)
+                                                unsigned long long k, unsigned long long ticks, int vec)
 {
     __shared__ double lds_pad[512];                      // 4 KB: an RCCL-like LDS footprint (keeps the block off CUs whose LDS is full)
     __shared__ int ok;
@@ -120,14 +143,33 @@ __global__ __launch_bounds__(512) void k_reduce(PeerTable P, int nranks, int ran
     __syncthreads();
     if (ok) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");    // the peers' slots were written by other processes' kernels
-        for (size_t i = (size_t)blockIdx.x * 512 + threadIdx.x; i < count; i += (size_t)gridDim.x * 512) {
-            double s;
-            if (root >= 0) s = dslot(P, root, k)[i];
-            else {
-                s = dslot(P, 0, k)[i];
-                for (int r = 1; r < nranks; r++) s += dslot(P, r, k)[i];            // rank order: every rank forms the same bits
+        if (!vec) {
+            for (size_t i = (size_t)blockIdx.x * 512 + threadIdx.x; i < count; i += (size_t)gridDim.x * 512) {
+                double sl = dslot(P, root >= 0 ? root : 0, k)[i];
+                if (root < 0) for (int r = 1; r < nranks; r++) sl += dslot(P, r, k)[i];
+                recv[i] = sl;
             }
-            recv[i] = s;
+            count = 0;
+        }
+        const size_t n2 = count / 2, stride = (size_t)gridDim.x * 512;
+        double2 *r2 = reinterpret_cast<double2 *>(recv);
+        for (size_t i = (size_t)blockIdx.x * 512 + threadIdx.x; i < n2; i += 4 * stride) {
+            double2 acc[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) if (i + u * stride < n2) acc[u] = reinterpret_cast<const double2 *>(dslot(P, root >= 0 ? root : 0, k))[i + u * stride];
+            if (root < 0)
+                for (int r = 1; r < nranks; r++) {                                  // rank order: every rank forms the same bits
+                    const double2 *p2 = reinterpret_cast<const double2 *>(dslot(P, r, k));
+#pragma unroll
+                    for (int u = 0; u < 4; u++) if (i + u * stride < n2) { const double2 v = p2[i + u * stride]; acc[u].x += v.x; acc[u].y += v.y; }
+                }
+#pragma unroll
+            for (int u = 0; u < 4; u++) if (i + u * stride < n2) r2[i + u * stride] = acc[u];
+        }
+        if ((count & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+            double sl = dslot(P, root >= 0 ? root : 0, k)[count - 1];
+            if (root < 0) for (int r = 1; r < nranks; r++) sl += dslot(P, r, k)[count - 1];
+            recv[count - 1] = sl;
         }
     }
     if (lds_pad[(threadIdx.x * 7) & 511] < 0.0) recv[0] = 0.0;                      // (never true: keeps the LDS array alive)
@@ -218,9 +260,10 @@ ncclResult_t collective(const void *send, void *recv, size_t count, ncclDataType
         if (count * sizeof(double) > kDevSlotBytes) return ncclInvalidArgument;
         const unsigned long long k = c->ops++;
         const unsigned long long ticks = (unsigned long long)(c->timeout_s * 1e8);          // wall_clock64: 100 MHz
-        const int nb_in = (int)std::min<size_t>(8, (count + 255) / 256 ? (count + 255) / 256 : 1);
-        hipLaunchKernelGGL(k_copy_in, dim3(nb_in), dim3(256), 0, stream, c->peers, c->nranks, c->rank, static_cast<const double *>(send), count, k, ticks);
-        hipLaunchKernelGGL(k_reduce, dim3(c->red_blocks), dim3(512), 0, stream, c->peers, c->nranks, c->rank, root, static_cast<double *>(recv), count, k, ticks);
+        const int vec = (((uintptr_t)send | (uintptr_t)recv) & 15) == 0 ? 1 : 0;
+        const int nb_in = (int)std::max<size_t>(1, std::min<size_t>((size_t)c->red_blocks, (count / 2 + 511) / 512));
+        hipLaunchKernelGGL(k_copy_in, dim3(nb_in), dim3(512), 0, stream, c->peers, c->nranks, c->rank, static_cast<const double *>(send), count, k, ticks, vec);
+        hipLaunchKernelGGL(k_reduce, dim3(c->red_blocks), dim3(512), 0, stream, c->peers, c->nranks, c->rank, root, static_cast<double *>(recv), count, k, ticks, vec);
         return hipGetLastError() == hipSuccess ? ncclSuccess : ncclUnhandledCudaError;
     }
     Op *op = new Op{c, c->ops++, count, root};
