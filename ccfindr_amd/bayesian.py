@@ -498,9 +498,11 @@ def vb_factorize(mat, ranks=2, nrun=1, verbose=2, progress_bar=True, initializer
                 # units' threads cut the same pair side by side
                 from .engine import sweep_workgroups
                 n_wg = sweep_workgroups(device)
-                for g in sorted({geometry_rank_for(r, bundle["classes"]) or int(r) for r in bundle["ranks"]}):
-                    for side in (1, 0):
-                        bundle["mat"].preload_layout(side, g, n_wg, device)
+                # (the two sides of a geometry side by side, as engine creation cuts them)
+                pieces = [(side, g) for g in sorted({geometry_rank_for(r, bundle["classes"]) or int(r) for r in bundle["ranks"]})
+                          for side in (1, 0)]
+                with ThreadPoolExecutor(max_workers=2) as cutters:
+                    list(cutters.map(lambda pc: bundle["mat"].preload_layout(pc[0], pc[1], n_wg, device), pieces))
             units = [(irun, int(r)) for irun in range(1, nrun + 1) for r in bundle["ranks"]]
             units.sort(key=lambda u: -u[1])                                      # longest first
             with ThreadPoolExecutor(max_workers=bundle["concurrent"]) as pool:

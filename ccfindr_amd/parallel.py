@@ -313,8 +313,23 @@ def vb_factorize_sharded(mat, ranks=2, nrun=1, verbose=0, initializer="random", 
             if not sharing and int(concurrent) > 1 and not X.is_shell:
                 # nobody to share with, but several units in flight: cut (and upload) the sweep's layouts once, here, instead of
                 # letting the first units' threads cut the same pair side by side
-                for pc in pieces:
-                    X.preload_layout(pc[1], pc[0], n_wg, device)
+                # (the two sides of a geometry side by side, as engine creation cuts them: each cut is memory-bound before it uses
+                # every host thread, and a side's upload runs beside the other side's cut)
+                X.prepare_async()
+                errs = []
+
+                def cut(pc):
+                    try:
+                        X.preload_layout(pc[1], pc[0], n_wg, device)
+                    except BaseException as exc:             # noqa: BLE001
+                        errs.append(exc)
+                ths = [threading.Thread(target=cut, args=(pc,)) for pc in pieces]
+                for th in ths:
+                    th.start()
+                for th in ths:
+                    th.join()
+                if errs:
+                    raise errs[0]
         except BaseException as exc:                      # noqa: BLE001 -- carried through the process group below
             layout_error = exc
     if warm is not None:
