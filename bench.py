@@ -500,7 +500,8 @@ def main():
     if world > 1 and local_world() > 1 and not os.environ.get("VBNMF_HOST_THREADS"):
         # the node's ranks ingest and cut side by side: each takes its share of the host's cores (default: up to 32 each)
         from ccfindr_amd.engine import set_host_threads
-        set_host_threads(max(1, len(os.sched_getaffinity(0)) // local_world()))
+        from ccfindr_amd.node import usable_cores as node_cores
+        set_host_threads(max(1, min(32, node_cores() // local_world())))       # (affinity mask and cgroup quota)
     name, X, r = make_workload(args.small, world, local_rank)
     if args.rank > 0 and args.rank != r:
         r = args.rank

@@ -254,10 +254,7 @@ def vb_factorize_sharded(mat, ranks=2, nrun=1, verbose=0, initializer="random", 
                 # once).  Layouts and cell order do not depend on the thread count.
                 from .engine import host_threads, set_host_threads
                 builders_here = max(1, len(set(b for b in builder_of.values() if b in my_node)))
-                try:
-                    cores = len(os.sched_getaffinity(0))
-                except (AttributeError, OSError):
-                    cores = os.cpu_count() or 1
+                cores = shm.usable_cores()                   # (affinity mask AND cgroup quota)
                 cores = int(os.environ.get("VBNMF_TEST_NODE_CORES") or 0) or cores        # test hook: pretend the node has this many
                 want = min(128, cores // builders_here)
                 lifted = want > host_threads() and not os.environ.get("VBNMF_HOST_THREADS")
