@@ -244,6 +244,7 @@ struct vbnmf_engine {
     // per-slice column sums of sw (csl) and their per-workgroup sums (csum); both tables of block partials alternate.
     double *csl = nullptr, *csum = nullptr;  // [A.n_slices][R], [n_wg][R]
     bool pair = false;
+    bool stream_nt = false;                  // the sweeps read the entry stream non-temporally (kernels.h: ld_stream)
     uint4 *upd_tab = nullptr;                // k_update2's work table, one row per block (build_update_table)
     int32_t upd_stride4 = 0, upd_V = 0, upd_ids_off = 0;
     int ub = kUpdateBlocks;           // blocks of the update kernels (one per CU; VBNMF_UPDATE_BLOCKS for experiments)
@@ -429,6 +430,7 @@ SweepSide sweep_side_args(const vbnmf_engine *e, const DeviceSide &S, bool gene_
         P.pull_ends = std::min(k, e->NT / 64);
     }
     P.logterm = gene_side ? 1 : 0;
+    P.stream_nt = e->stream_nt ? 1 : 0;
     P.n_wg = S.n_wg;
     P.logtab = e->logtab;
     P.stop = e->run_active ? (e->stop_ptr ? e->stop_ptr : &e->ctl->stop) : nullptr;
@@ -477,7 +479,7 @@ int launch_sweep_r(vbnmf_engine *e, const SweepSide &a, const SweepSide &b)
     X(40) X(48) X(56) X(64)
 // every padded rank: up to 32 by 2 (one lane per task), 40..64 by 8 (two lanes), 80..128 by 16 (four lanes)
 #ifdef VBNMF_DEV_FEW_RANKS              /* development builds only: a few ranks, for a compile check in a minute */
-#define VBNMF_FOR_EACH_R(X) X(4) X(10) X(20) X(48) X(80)
+#define VBNMF_FOR_EACH_R(X) X(4) X(6) X(8) X(10) X(20) X(48) X(80)
 #else
 #define VBNMF_FOR_EACH_R(X) VBNMF_FOR_EACH_R_UP_TO_64(X) X(80) X(96) X(112) X(128)
 #endif
@@ -1119,6 +1121,18 @@ int vbnmf_engine_create_geom(const vbnmf_matrix *X, int64_t cb, int64_t ce, int6
         e->xlx = X->xlx;
     } else {
         e->xlx = sum_xlogx(X->M, cb, ce);
+    }
+    {
+        // Cache policy of the entry stream (kernels.h: ld_stream).  What a step moves between two uses of a line: both sides' entry
+        // streams and the per-task partial rows, written and read back.  Beyond the Infinity Cache (256 MB: the headline moves
+        // 410 + 2 x 75 MB) the stream is read non-temporally so that the partial rows and the state stay on the die; inside it
+        // (C2: 130 MB; 5 000 x 20 000: 61 MB) the stream itself stays resident from step to step and the default policy is the
+        // faster one (profiles/r05_nt_ab.txt, r05_small_nt_ab.txt).  VBNMF_STREAM_NT=0 / 1 forces it.
+        const double entry_b = e->wide ? 12.0 : 4.0;
+        const double moved = entry_b * ((double)e->A.n_slots + (double)e->B.n_slots) +
+                             2.0 * 8.0 * e->R * 64.0 * ((double)e->A.n_slices + (double)e->B.n_slices);
+        e->stream_nt = moved > 200e6;
+        if (const char *v = getenv("VBNMF_STREAM_NT")) e->stream_nt = v[0] == '1';
     }
     static_assert(kLdsRowBase == kLdsReserveBytes, "host and device disagree on the sweep's LDS reserve");
     e->lds_bytes = kLdsRowBase + std::max((size_t)e->A.block_width * e->A.row_slots, (size_t)e->B.block_width * e->B.row_slots) * 16;

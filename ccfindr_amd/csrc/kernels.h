@@ -64,6 +64,7 @@ struct SweepSide {
     int32_t n_wg;
     const LogTabEntry *logtab;     // [128] ln table (staged at the front of LDS)
     int32_t pull_ends;             // the youngest waves pull slices from the short end of a segment's list (take_ticket_ends)
+    int32_t stream_nt;             // the entry stream is read with the non-temporal policy (it does not fit the Infinity Cache)
     const int32_t *stop;           // device-driven loop: the sweep returns at once when *stop != 0 (or null)
     unsigned long long *dbg;       // diagnostic: [n_wg][2 + 2*waves] 100 MHz timestamps, or null
 };
@@ -106,15 +107,19 @@ __device__ __forceinline__ void pin_offsets(Group4 &g)
 #ifndef VBNMF_PREFETCH2
 #define VBNMF_PREFETCH2 0
 #endif
-__device__ __forceinline__ uint4 ld_stream(const uint4 *p)
+// nt (wave-uniform, SweepSide::stream_nt): the engine sets it when the step's streams do NOT fit the Infinity Cache.  Where they do
+// (C2: 130 MB of entries; 5 000 x 20 000: 61 MB) the default policy keeps the stream itself on the die from one step to the next, and
+// the non-temporal loads cost 1-3.5 % (profiles/r05_small_nt_ab.txt).
+__device__ __forceinline__ uint4 ld_stream(const uint4 *p, int nt)
 {
 #if VBNMF_STREAM_NT
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
-    return make_uint4(v.x, v.y, v.z, v.w);
-#else
-    return *p;
+    if (nt) {
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+        return make_uint4(v.x, v.y, v.z, v.w);
+    }
 #endif
+    return *p;
 }
 // The per-task partial rows (75 MB per sweep at the headline size) are written once and gathered back by the update kernels.
 // VBNMF_PART_NT=1 stores them with the non-temporal policy (experiment: profiles/r05_part_nt_ab.txt).
@@ -152,15 +157,16 @@ __device__ __forceinline__ void st_once(double *p, double v)
     *p = v;
 #endif
 }
-__device__ __forceinline__ double2 ld_stream(const double2 *p)
+__device__ __forceinline__ double2 ld_stream(const double2 *p, int nt)
 {
 #if VBNMF_STREAM_NT
-    typedef double f64x2 __attribute__((ext_vector_type(2)));
-    const f64x2 v = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(p));
-    return make_double2(v.x, v.y);
-#else
-    return *p;
+    if (nt) {
+        typedef double f64x2 __attribute__((ext_vector_type(2)));
+        const f64x2 v = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(p));
+        return make_double2(v.x, v.y);
+    }
 #endif
+    return *p;
 }
 // LDS image of the sweep: [0, kLdsTabBytes) the ln table, then kLdsEvSlots per-slice evidence
 // partials, the slice ticket counter, and from kLdsRowBase on the staged factor block.
@@ -453,6 +459,7 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
     // src/vbnmf_update.cpp:53), and sum_i ew_ik = (n aw + sum_i sw_ik) / bew_k is known without the W update having run.
     constexpr bool CS = (EV == 1) && LOGTERM;
     const bool cs_on = CS && S.csl != nullptr;             // (workgroup-uniform)
+    const int snt = S.stream_nt;                           // the entry stream's cache policy (ld_stream)
     // The per-slice rows are added up per workgroup by colsum_finish(): NOT here -- their read-back is a global round trip,
     // and inside this side's chunk ends it held the whole workgroup for 3 us at rank 10 and 14 us at rank 20 (round 5,
     // profiles/r05_pair_ab.txt).  k_sweep hands the job to the CELL side, whose wave 1 runs it when it has run out of
@@ -527,7 +534,7 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
                 const int ngf = (EV == 3) ? 0 : min(ng, (S.slice_fast[s] & 0xFFFF) >> 2);      // groups inside the leading stretch of ones
                 int g = 0;
                 for (; g < ngf; g++) {
-                    const Group4 a = unpack4<R>(ld_stream(E + (size_t)g * 64), share);
+                    const Group4 a = unpack4<R>(ld_stream(E + (size_t)g * 64, snt), share);
                     lds_row<R>(ldsG, a.o0, g0); sweep_entry<R, false, true, SP>(T, ldsG, g0, 1.0, LOGTERM);
                     lds_row<R>(ldsG, a.o1, g0); sweep_entry<R, false, true, SP>(T, ldsG, g0, 1.0, LOGTERM);
                     if (LOGTERM) renorm_product<R>(T);
@@ -536,7 +543,7 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
                     if (LOGTERM) renorm_product<R>(T);
                 }
                 for (; g < ng; g++) {
-                    const Group4 a = unpack4<R>(ld_stream(E + (size_t)g * 64), share);
+                    const Group4 a = unpack4<R>(ld_stream(E + (size_t)g * 64, snt), share);
                     lds_row<R>(ldsG, a.o0, g0); sweep_entry<R, EV == 3, false, SP>(T, ldsG, g0, (double)a.c0, LOGTERM);
                     lds_row<R>(ldsG, a.o1, g0); sweep_entry<R, EV == 3, false, SP>(T, ldsG, g0, (double)a.c1, LOGTERM);
                     lds_row<R>(ldsG, a.o2, g0); sweep_entry<R, EV == 3, false, SP>(T, ldsG, g0, (double)a.c2, LOGTERM);
@@ -547,12 +554,12 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
             } else if (!WIDE) {
                 double2 g1[R / 2];
                 const uint4 *E = reinterpret_cast<const uint4 *>(S.packed + off) + tlane;
-                Group4 a = unpack4<R>(ld_stream(E), share), b = unpack4<R>(ld_stream(E + (size_t)min(1, ng - 1) * 64), share);
+                Group4 a = unpack4<R>(ld_stream(E, snt), share), b = unpack4<R>(ld_stream(E + (size_t)min(1, ng - 1) * 64, snt), share);
 #if VBNMF_PREFETCH2
                 // the entry stream TWO trips ahead: the groups of trip p + 1 are on their way (ec, ed) when trip p issues the
                 // loads of trip p + 2 -- with the stream read non-temporally every group comes from HBM, 1.5-2 us under load,
                 // about what ONE trip of three interleaved waves takes
-                uint4 ec = ld_stream(E + (size_t)min(2, ng - 1) * 64), ed = ld_stream(E + (size_t)min(3, ng - 1) * 64);
+                uint4 ec = ld_stream(E + (size_t)min(2, ng - 1) * 64, snt), ed = ld_stream(E + (size_t)min(3, ng - 1) * 64, snt);
 #endif
                 lds_row<R>(ldsG, a.o0, g0);
                 // FENCE keeps the machine scheduler from sinking a row's LDS reads down to their first
@@ -563,10 +570,10 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
                 // MODE: 0 general, 1 the leading ones, 2 the ones-or-twos behind them (gene side only: it defers the logarithm)
 #define VBNMF_ENTRY(MODE, gv, cnt) sweep_entry<R, EV == 3, (MODE) == 1, SP, (MODE) == 2>(T, ldsG, gv, (double)(cnt), LOGTERM); if ((MODE) == 2 && LOGTERM) renorm_product<R>(T); VBNMF_FENCE()
 #if VBNMF_PREFETCH2
-#define VBNMF_TRIP_LOADS const uint4 fc = ld_stream(E + (size_t)min(2 * p + 4, ng - 1) * 64), fd = ld_stream(E + (size_t)min(2 * p + 5, ng - 1) * 64);
+#define VBNMF_TRIP_LOADS const uint4 fc = ld_stream(E + (size_t)min(2 * p + 4, ng - 1) * 64, snt), fd = ld_stream(E + (size_t)min(2 * p + 5, ng - 1) * 64, snt);
 #define VBNMF_TRIP_ROTATE ec = fc; ed = fd;
 #else
-#define VBNMF_TRIP_LOADS const uint4 ec = ld_stream(E + (size_t)min(2 * p + 2, ng - 1) * 64), ed = ld_stream(E + (size_t)min(2 * p + 3, ng - 1) * 64);
+#define VBNMF_TRIP_LOADS const uint4 ec = ld_stream(E + (size_t)min(2 * p + 2, ng - 1) * 64, snt), ed = ld_stream(E + (size_t)min(2 * p + 3, ng - 1) * 64, snt);
 #define VBNMF_TRIP_ROTATE
 #endif
 #define VBNMF_TRIP(MODE, PIN)                                                                     \
@@ -629,8 +636,8 @@ __device__ __forceinline__ void sweep_side(const SweepSide &S, double2 *__restri
                 const double2 *V = reinterpret_cast<const double2 *>(S.wval + off) + tlane * 2;
                 const uint32_t rowb = (uint32_t)S.row_slots * 16u;     // bytes per staged row
                 for (int g = 0; g < ng; g++) {
-                    const uint4 c = ld_stream(E + (size_t)g * 64);
-                    const double2 v0 = ld_stream(V + (size_t)g * 128), v1 = ld_stream(V + (size_t)g * 128 + 1);
+                    const uint4 c = ld_stream(E + (size_t)g * 64, snt);
+                    const double2 v0 = ld_stream(V + (size_t)g * 128, snt), v1 = ld_stream(V + (size_t)g * 128 + 1, snt);
                     lds_row<R>(ldsG, c.x * rowb + share, g0);
                     lds_row<R>(ldsG, c.y * rowb + share, g1);
                     sweep_entry<R, EV == 3, false, SP>(T, ldsG, g0, v0.x, LOGTERM);
