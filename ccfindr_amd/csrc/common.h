@@ -172,8 +172,10 @@ constexpr int rank_shares(int RT) { return RT <= 32 ? 1 : (RT <= 64 ? 2 : 4); }
 // bank slots so that rows congruent mod 16 (and only those) start in the same slot.
 constexpr int lds_row_bytes(int R) { return ((R / 2) | 1) * 16; }
 // LDS the sweep keeps for itself in front of the factor block: the 128-entry ln table (2048 B),
-// 256 per-slice evidence partials (2048 B) and the slice ticket counter (16 B).
-constexpr int kLdsReserveBytes = 4112;
+// 128 per-slice evidence partials (1024 B; 256 until round 5: a segment holds 24-35 slices at the headline size, and 1 KB more of
+// block is twelve more factor rows -- 20 000 genes now fall in 10 blocks instead of 11, 50 000 cells in 25 instead of 26) and the slice
+// ticket counter (16 B).
+constexpr int kLdsReserveBytes = 3088;
 // Threads per workgroup of the sweep kernel at padded rank R: as many waves per SIMD as the
 // kernel's register need (factor row + accumulators + two gathered rows, ~14 R + 20 VGPRs) allows
 // without spilling: 4 waves/SIMD up to R = 4, 3 up to 14 (measured on the C3 matrix, round 2: 768 against 512 threads

@@ -107,6 +107,9 @@ __device__ __forceinline__ void pin_offsets(Group4 &g)
 #ifndef VBNMF_PREFETCH2
 #define VBNMF_PREFETCH2 0
 #endif
+#ifndef VBNMF_END_WB
+#define VBNMF_END_WB 0
+#endif
 // nt (wave-uniform, SweepSide::stream_nt): the engine sets it when the step's streams do NOT fit the Infinity Cache.  Where they do
 // (C2: 130 MB of entries; 5 000 x 20 000: 61 MB) the default policy keeps the stream itself on the die from one step to the next, and
 // the non-temporal loads cost 1-3.5 % (profiles/r05_small_nt_ab.txt).
@@ -171,7 +174,7 @@ __device__ __forceinline__ double2 ld_stream(const double2 *p, int nt)
 // LDS image of the sweep: [0, kLdsTabBytes) the ln table, then kLdsEvSlots per-slice evidence
 // partials, the slice ticket counter, and from kLdsRowBase on the staged factor block.
 constexpr uint32_t kLdsTabBytes = kLogTabSize * sizeof(LogTabEntry);
-constexpr int kLdsEvSlots = 256;
+constexpr int kLdsEvSlots = 128;
 constexpr uint32_t kLdsEvBase = kLdsTabBytes;
 constexpr uint32_t kLdsCtrBase = kLdsEvBase + kLdsEvSlots * sizeof(double);
 constexpr uint32_t kLdsRowBase = kLdsCtrBase + 16;
@@ -715,6 +718,11 @@ __global__ __launch_bounds__(NT) void k_sweep(const SweepSide A, const SweepSide
     if (A.stop && *A.stop) return;               // the driver loop has ended: leave the statistics as they are
     sweep_side<R, WIDE, true, NT, 1, SP>(A, ldsG);      // lanes own genes: statistics sw + the sum x log(wth) (+ rows of column sums)
     sweep_side<R, WIDE, false, NT, 1, SP>(B, ldsG, &A); // lanes own cells: statistics sh (+ the gene side's column sums added up)
+#if VBNMF_END_WB
+    // experiment (profiles/r05_end_wb_ab.txt): every workgroup asks its XCD's L2 to write back when IT is done, so that the
+    // release at the kernel's end -- the 6.5 us between this kernel and the next -- finds little left to write
+    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
 }
 
 // One side alone (ML-NMF: its H and W updates are sequential, reference R/factorize.R:8-24, so each needs its

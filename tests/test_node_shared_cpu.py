@@ -220,3 +220,24 @@ def test_layouts_do_not_depend_on_the_host_thread_count():
         set_host_threads(0)
     for nt in (3, 7, 0):
         assert blobs[nt][0] == blobs[1][0] and blobs[nt][1] == blobs[1][1], nt
+
+
+def test_usable_cores_follows_the_affinity_mask_and_the_cgroup_quota(monkeypatch, tmp_path):
+    """The layout builder of a node takes its waiting peers' cores -- as many as this process may REALLY use: the affinity mask
+    cut down to the cgroup's CPU quota (round 5: 128 visible CPUs under a quota of 16 made the builder's 128 threads cut the
+    layouts in 0.39 s instead of 0.18)."""
+    import builtins
+    import os
+    from ccfindr_amd import node
+    n = node.usable_cores()
+    assert 1 <= n <= len(os.sched_getaffinity(0))
+    real_open = builtins.open
+
+    def fake_open(path, *a, **k):
+        if path == "/sys/fs/cgroup/cpu.max":
+            f = tmp_path / "cpu.max"
+            f.write_text("300000 100000\n")                # a quota of three cores
+            return real_open(f, *a, **k)
+        return real_open(path, *a, **k)
+    monkeypatch.setattr(builtins, "open", fake_open)
+    assert node.usable_cores() == min(3, len(os.sched_getaffinity(0)))
