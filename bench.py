@@ -124,8 +124,20 @@ def node_shared_matrix(tag, make, world, local_rank=None):
     base = os.path.join(shm.shm_dir(), f"vbnmf_bench_{tag}_{box[0]}")
     names = {k: f"{base}_{k}.npy" for k in ("indptr", "indices", "data", "shape")}
     X = None
+    shared_ok = True
     if local_rank == 0:
         X = generate()
+        # room in the node's memory file system for the three arrays (a container may give /dev/shm 64 MB: writing past a full
+        # tmpfs fails) -- decided before anything is written
+        need = X.nnz * 12 + 8 * (X.shape[1] + 1) + 4096
+        shared_ok = shm.free_bytes() > 1.1 * need
+    votes = [None] * world
+    dist.all_gather_object(votes, bool(shared_ok))               # every rank learns every node's answer: one decision for the run
+    if not all(votes):
+        if dist.get_rank() == 0:
+            print(f"bench: {tag}: no room in {shm.shm_dir()} for the shared matrix; every rank generates its own copy", file=sys.stderr)
+        return X if X is not None else generate()
+    if local_rank == 0:
         idt = np.int32 if X.nnz < 2 ** 31 - 1 else np.int64
         np.save(names["indptr"], X.indptr.astype(idt, copy=False))
         np.save(names["indices"], X.indices.astype(idt, copy=False))
