@@ -1032,6 +1032,20 @@ int vbnmf_engine_create_geom(const vbnmf_matrix *X, int64_t cb, int64_t ce, int6
     if (int rc = sweep_workgroups(device, e->partitioned, e->n_wg)) { delete e; return rc; }
     int rc = VBNMF_OK;
     auto bail = [&](int code) { vbnmf_engine_destroy(e); return code; };
+    {
+        // The engine's stream first: everything that initialises the engine's own buffers below is queued ON it
+        // (hipMemsetAsync), so it is ordered with the engine's kernels.  A plain hipMemset goes to the device's null stream,
+        // which this non-blocking stream does not wait for, and may return before the fill has run: with several host threads
+        // creating engines side by side (vb_factorize(concurrent=K)) a fill queued behind the other threads' null-stream work
+        // could land AFTER the engine's first kernels had written the buffer -- zeroed block partials, a different trajectory
+        // (seen once in round 5, tests/test_gpu_end_to_end.py::test_concurrent_units_give_the_same_result).
+        hipError_t hs;
+        if ((hs = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)) != hipSuccess ||
+            (hs = hipEventCreate(&e->ev0)) != hipSuccess || (hs = hipEventCreate(&e->ev1)) != hipSuccess ||
+            (hs = hipEventCreate(&e->ev2)) != hipSuccess || (hs = hipEventCreate(&e->ev3)) != hipSuccess)
+            return bail(fail(VBNMF_ERR_HIP, "engine setup failed: %s", hipGetErrorString(hs)));
+        e->own_stream = true;
+    }
 
     try {
         std::vector<int32_t> part_order;                         // a partition orders its own cells (both sides alike)
@@ -1149,12 +1163,12 @@ int vbnmf_engine_create_geom(const vbnmf_matrix *X, int64_t cb, int64_t ce, int6
         if (e->fold || e->pair) {
             if ((rc = dev_alloc(&e->bpW_alt, (size_t)kUpdateBlocks * (e->R + 2))) ||
                 (rc = dev_alloc(&e->bpH_alt, (size_t)kUpdateBlocks * (e->R + 2)))) return bail(rc);
-            if (hipMemset(e->bpW_alt, 0, (size_t)kUpdateBlocks * (e->R + 2) * sizeof(double)) != hipSuccess ||
-                hipMemset(e->bpH_alt, 0, (size_t)kUpdateBlocks * (e->R + 2) * sizeof(double)) != hipSuccess) return bail(fail(VBNMF_ERR_HIP, "hipMemset failed"));
+            if (hipMemsetAsync(e->bpW_alt, 0, (size_t)kUpdateBlocks * (e->R + 2) * sizeof(double), e->stream) != hipSuccess ||
+                hipMemsetAsync(e->bpH_alt, 0, (size_t)kUpdateBlocks * (e->R + 2) * sizeof(double), e->stream) != hipSuccess) return bail(fail(VBNMF_ERR_HIP, "hipMemsetAsync failed"));
         }
         if (e->pair) {
             if ((rc = dev_alloc(&e->csl, (size_t)std::max<int64_t>(e->A.n_slices, 1) * e->R)) || (rc = dev_alloc(&e->csum, (size_t)e->n_wg * e->R))) return bail(rc);
-            if (hipMemset(e->csum, 0, (size_t)e->n_wg * e->R * sizeof(double)) != hipSuccess) return bail(fail(VBNMF_ERR_HIP, "hipMemset failed"));
+            if (hipMemsetAsync(e->csum, 0, (size_t)e->n_wg * e->R * sizeof(double), e->stream) != hipSuccess) return bail(fail(VBNMF_ERR_HIP, "hipMemsetAsync failed"));
         }
     }
 
@@ -1170,23 +1184,23 @@ int vbnmf_engine_create_geom(const vbnmf_matrix *X, int64_t cb, int64_t ce, int6
     else if ((rc = dev_alloc(&e->epart, 2 * (size_t)e->n_wg))) return bail(rc);
     hipError_t he;
     if ((he = hipHostMalloc((void **)&e->h_out, kHostOut * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess ||
-        (he = hipHostGetDevicePointer((void **)&e->h_out_dev, e->h_out, 0)) != hipSuccess ||
-        (he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)) != hipSuccess ||
-        (he = hipEventCreate(&e->ev0)) != hipSuccess || (he = hipEventCreate(&e->ev1)) != hipSuccess ||
-        (he = hipEventCreate(&e->ev2)) != hipSuccess || (he = hipEventCreate(&e->ev3)) != hipSuccess)
+        (he = hipHostGetDevicePointer((void **)&e->h_out_dev, e->h_out, 0)) != hipSuccess)
         return bail(fail(VBNMF_ERR_HIP, "engine setup failed: %s", hipGetErrorString(he)));
-    e->own_stream = true;
     std::memset(e->h_out, 0, kHostOut * sizeof(double));
     if (getenv("VBNMF_DEBUG_TIMES")) {
         e->dbg_count = 2 * (size_t)e->n_wg * (2 + 2 * (e->NT / 64));
         if ((rc = dev_alloc(&e->dbg, e->dbg_count))) return bail(rc);
     }
-    if ((he = hipMemset(e->ew, 0, nR * sizeof(double))) != hipSuccess || (he = hipMemset(e->dw, 0, nR * sizeof(double))) != hipSuccess ||
-        (he = hipMemset(e->dh, 0, mR * sizeof(double))) != hipSuccess || (he = hipMemset(e->bpW, 0, bpn * sizeof(double))) != hipSuccess ||
-        (he = hipMemset(e->bpH, 0, bpn * sizeof(double))) != hipSuccess || (he = hipMemset(e->red, 0, (size_t)red_alloc_count(e) * sizeof(double))) != hipSuccess)
-        return bail(fail(VBNMF_ERR_HIP, "hipMemset failed: %s", hipGetErrorString(he)));
-    if (e->epart_in_red && (he = hipMemcpy(e->red + e->red_count + kEvSlots, &e->lgx, sizeof(double), hipMemcpyHostToDevice)) != hipSuccess)
-        return bail(fail(VBNMF_ERR_HIP, "hipMemcpy failed: %s", hipGetErrorString(he)));
+    if ((he = hipMemsetAsync(e->ew, 0, nR * sizeof(double), e->stream)) != hipSuccess || (he = hipMemsetAsync(e->dw, 0, nR * sizeof(double), e->stream)) != hipSuccess ||
+        (he = hipMemsetAsync(e->dh, 0, mR * sizeof(double), e->stream)) != hipSuccess || (he = hipMemsetAsync(e->bpW, 0, bpn * sizeof(double), e->stream)) != hipSuccess ||
+        (he = hipMemsetAsync(e->bpH, 0, bpn * sizeof(double), e->stream)) != hipSuccess ||
+        (he = hipMemsetAsync(e->red, 0, (size_t)red_alloc_count(e) * sizeof(double), e->stream)) != hipSuccess)
+        return bail(fail(VBNMF_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(he)));
+    // (sum lgamma(x + 1) into its slot of the reduce buffer: BEHIND the fill above, on the same stream; e->lgx lives as long as the engine)
+    if (e->epart_in_red && (he = hipMemcpyAsync(e->red + e->red_count + kEvSlots, &e->lgx, sizeof(double), hipMemcpyHostToDevice, e->stream)) != hipSuccess)
+        return bail(fail(VBNMF_ERR_HIP, "hipMemcpyAsync failed: %s", hipGetErrorString(he)));
+    // creation ends with the engine's buffers in their initial state whatever else the device is doing
+    if ((he = hipStreamSynchronize(e->stream)) != hipSuccess) return bail(fail(VBNMF_ERR_HIP, "engine setup failed: %s", hipGetErrorString(he)));
     *out = e;
     return VBNMF_OK;
 }
@@ -1285,6 +1299,12 @@ int vbnmf_engine_set_stream(vbnmf_engine *e, void *stream)
 
 // column-major n x r (R matrix) -> device [n][R]; or r x m column-major (already index-major) -> [m][R].
 // perm (cell-indexed arrays only): device row p holds the caller's major perm[p] (the layout's order of the cells).
+// host threads for a conversion of a factor's arrays: one per 32 K elements (a 200 x 3 factor is not worth waking anyone for)
+static int state_threads(int64_t nmaj, int R)
+{
+    return (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), (nmaj * (int64_t)R) >> 15));
+}
+
 static void to_index_major(const double *src, int64_t nmaj, int r, int R, bool src_is_major_contiguous, double *dst,
                            const std::vector<int32_t> *perm = nullptr)
 {
@@ -1296,7 +1316,7 @@ static void to_index_major(const double *src, int64_t nmaj, int r, int R, bool s
             for (int k = 0; k < r; k++) d[k] = src_is_major_contiguous ? src[(size_t)S * r + k] : src[S + (size_t)k * nmaj];
             for (int k = r; k < R; k++) d[k] = 0.0;
         }
-    });
+    }, state_threads(nmaj, R));
 }
 
 static void to_index_major(const double *src, int64_t nmaj, int r, int R, bool src_is_major_contiguous, std::vector<double> &dst,
@@ -1318,7 +1338,7 @@ static void from_index_major(const double *src, int64_t nmaj, int r, int R, bool
                 if (dst_is_major_contiguous) dst[(size_t)D * r + k] = v; else dst[D + (size_t)k * nmaj] = v;
             }
         }
-    });
+    }, state_threads(nmaj, R));
 }
 
 static void from_index_major(const std::vector<double> &src, int64_t nmaj, int r, int R, bool dst_is_major_contiguous, double *dst,
@@ -1472,7 +1492,8 @@ int ensure_comm_resources(vbnmf_engine *e)
     if (!e->cstream) HIPCHECK(hipStreamCreateWithFlags(&e->cstream, hipStreamNonBlocking));
     if (!e->red_g) {
         if (int rc = dev_alloc(&e->red_g, (size_t)red_alloc_count(e))) return rc;
-        HIPCHECK(hipMemset(e->red_g, 0, (size_t)red_alloc_count(e) * sizeof(double)));
+        HIPCHECK(hipMemsetAsync(e->red_g, 0, (size_t)red_alloc_count(e) * sizeof(double), e->stream));      // (ordered with the engine's kernels; see engine creation)
+        HIPCHECK(hipStreamSynchronize(e->stream));
     }
     while (e->ev_ring.size() < 160) {
         hipEvent_t ev;
@@ -2679,33 +2700,57 @@ struct StatelessCache {
 };
 StatelessCache &stateless_cache() { static StatelessCache c; return c; }
 
-uint64_t hash_bytes(const void *data, size_t bytes, uint64_t seed)
+// Two independently seeded hashes of the same bytes in ONE pass over them (the stateless cache's 128-bit key).  Per 4 MB chunk
+// FOUR multiply-xorshift chains per seed, fed the chunk's 8-byte words in turn (word q goes to chain q mod 4), so eight independent
+// chains are in flight and a thread hashes at memory speed instead of at one multiply latency per word (a 3.7 MB dense matrix
+// -- the reference's shipped data set -- used to take 0.7 ms of every literal drop-in call); chains and chunks are combined in
+// order: the value does not depend on the thread count.  The seed starts EVERY chain of every chunk (not only the final combine),
+// so two seeds give two INDEPENDENT 64-bit hashes: contents that collide in a chain under one seed do not under the other
+// (tests/test_node_shared_cpu.py).  Small inputs are hashed by few threads (a thread is worth starting for a chunk or more).
+void hash_bytes2(const void *data, size_t bytes, uint64_t seed_a, uint64_t seed_b, uint64_t &out_a, uint64_t &out_b)
 {
-    // per-chunk multiply-xorshift over 8-byte words, chunks combined in order: independent of the thread count.  The seed
-    // starts every chunk's digest (not only the final combine), so two seeds give two INDEPENDENT 64-bit hashes: contents
-    // that collide in a chunk digest under one seed do not under the other (tests/test_cabi_symbols.py).
     const size_t chunk = (size_t)1 << 22;
     const size_t nchunks = (bytes + chunk - 1) / chunk;
-    std::vector<uint64_t> part(nchunks ? nchunks : 1, 0);
+    std::vector<uint64_t> part_a(nchunks ? nchunks : 1, 0), part_b(nchunks ? nchunks : 1, 0);
     const unsigned char *p = static_cast<const unsigned char *>(data);
+    constexpr uint64_t K = 0xFF51AFD7ED558CCDull, KL = 0xA24BAED4963EE407ull, KC = 0xC4CEB9FE1A85EC53ull;
     parallel_for((int64_t)nchunks, [&](int64_t b, int64_t e, int) {
         for (int64_t c = b; c < e; c++) {
             const size_t o = (size_t)c * chunk, len = std::min(chunk, bytes - o);
-            uint64_t h = seed ^ 0x9E3779B97F4A7C15ull ^ ((uint64_t)c * 0xD6E8FEB86659FD93ull);   // the seed enters EVERY chunk digest
+            const uint64_t salt = 0x9E3779B97F4A7C15ull ^ ((uint64_t)c * 0xD6E8FEB86659FD93ull);
+            uint64_t ha[4], hb[4];
+            for (int j = 0; j < 4; j++) { ha[j] = seed_a ^ salt ^ ((uint64_t)j * KL); hb[j] = seed_b ^ salt ^ ((uint64_t)j * KL); }
             size_t q = 0;
-            for (; q + 8 <= len; q += 8) {
+            for (; q + 32 <= len; q += 32) {
+                uint64_t w[4];
+                std::memcpy(w, p + o + q, 32);
+                for (int j = 0; j < 4; j++) {
+                    ha[j] = (ha[j] ^ w[j]) * K; hb[j] = (hb[j] ^ w[j]) * K;
+                    ha[j] ^= ha[j] >> 32; hb[j] ^= hb[j] >> 32;
+                }
+            }
+            for (int j = 0; q + 8 <= len; q += 8, j++) {
                 uint64_t w;
                 std::memcpy(&w, p + o + q, 8);
-                h = (h ^ w) * 0xFF51AFD7ED558CCDull;
-                h ^= h >> 32;
+                ha[j] = (ha[j] ^ w) * K; hb[j] = (hb[j] ^ w) * K;
+                ha[j] ^= ha[j] >> 32; hb[j] ^= hb[j] >> 32;
             }
-            for (; q < len; q++) { h = (h ^ p[o + q]) * 0x100000001B3ull; }
-            part[c] = h;
+            for (; q < len; q++) { ha[0] = (ha[0] ^ p[o + q]) * 0x100000001B3ull; hb[0] = (hb[0] ^ p[o + q]) * 0x100000001B3ull; }
+            uint64_t da = ha[0], db = hb[0];
+            for (int j = 1; j < 4; j++) { da = (da ^ ha[j]) * KC; da ^= da >> 29; db = (db ^ hb[j]) * KC; db ^= db >> 29; }
+            part_a[c] = da; part_b[c] = db;
         }
     });
-    uint64_t h = seed;
-    for (uint64_t v : part) { h = (h ^ v) * 0xC4CEB9FE1A85EC53ull; h ^= h >> 29; }
-    return h;
+    uint64_t ha = seed_a, hb = seed_b;
+    for (uint64_t v : part_a) { ha = (ha ^ v) * KC; ha ^= ha >> 29; }
+    for (uint64_t v : part_b) { hb = (hb ^ v) * KC; hb ^= hb >> 29; }
+    out_a = ha; out_b = hb;
+}
+uint64_t hash_bytes(const void *data, size_t bytes, uint64_t seed)
+{
+    uint64_t a, b;
+    hash_bytes2(data, bytes, seed, ~seed, a, b);
+    return a;
 }
 
 bool stateless_cache_enabled()
@@ -2775,8 +2820,8 @@ int with_dense(int64_t n, int64_t m, int32_t r, const double *X, const std::func
     StatelessCache &C = stateless_cache();
     std::lock_guard<std::mutex> g(C.mu);
     const bool cache = stateless_cache_enabled();
-    const uint64_t h = cache ? hash_bytes(X, (size_t)n * (size_t)m * sizeof(double), 0x64656E7365ull) : 0;
-    const uint64_t h2 = cache ? hash_bytes(X, (size_t)n * (size_t)m * sizeof(double), 0x3243F6A8885A308Dull) : 0;
+    uint64_t h = 0, h2 = 0;
+    if (cache) hash_bytes2(X, (size_t)n * (size_t)m * sizeof(double), 0x64656E7365ull, 0x3243F6A8885A308Dull, h, h2);
     if (!cache) C.drop();
     vbnmf_engine *e = nullptr;
     int rc = stateless_engine(0, n, m, 0, h, h2, nullptr, X, r, [&](vbnmf_matrix **M) { return vbnmf_matrix_from_dense(n, m, X, M); }, &e);
@@ -2800,10 +2845,8 @@ int with_csc(int64_t n, int64_t m, int32_t r, const int32_t *p, const int32_t *i
     if (nnz > 0 && (!i || !x)) return fail(VBNMF_ERR_BAD_ARG, "a CSC slot pointer is NULL");
     uint64_t h = 0, h2 = 0;
     if (cache) {
-        h = hash_bytes(i, (size_t)nnz * sizeof(int32_t), 0x637363ull);
-        h = hash_bytes(x, (size_t)nnz * sizeof(double), h);
-        h2 = hash_bytes(i, (size_t)nnz * sizeof(int32_t), 0x3243F6A8885A308Dull);
-        h2 = hash_bytes(x, (size_t)nnz * sizeof(double), h2);
+        hash_bytes2(i, (size_t)nnz * sizeof(int32_t), 0x637363ull, 0x3243F6A8885A308Dull, h, h2);
+        hash_bytes2(x, (size_t)nnz * sizeof(double), h, h2, h, h2);
     }
     if (!cache) C.drop();
     vbnmf_engine *e = nullptr;

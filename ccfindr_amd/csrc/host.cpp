@@ -17,6 +17,9 @@
 #include <unistd.h>
 
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <pthread.h>
 #include <system_error>
 #include <cmath>
 #include <cstdlib>
@@ -75,37 +78,118 @@ int host_threads()
     return n;
 }
 
+// Fork-join over [0, count) on a pool of worker threads that outlives the call.  (Until round 5 every call started and joined its
+// own std::threads: ~25 us apiece, i.e. the better part of a millisecond per call on 32 threads -- more than the work itself in
+// the state conversions of set_state / get_state, 3 + 5 ms of every literal drop-in call on a 2 000 x 5 000 matrix, and several
+// dozen times per layout.)  The pieces of a call are the same whatever runs them: piece t covers [count t / nt, count (t+1) / nt)
+// and is handed t as its `tid`, so results that depend on the split (none should; tests/test_node_shared_cpu.py) do not change.
+// The caller runs piece 0 itself and then HELPS: while its call is unfinished it takes queued pieces -- its own or another
+// caller's (engine creation cuts two layouts on two host threads; a piece may itself call parallel_for) -- so a call completes
+// even with no worker at all (thread limit reached; the child of a fork, which inherits the queue's bookkeeping but no threads).
+namespace {
+struct ForkJoin {                                   // one call
+    std::atomic<int> left{0};
+    std::exception_ptr first;
+    std::mutex first_mu;
+};
+struct PoolTask { const std::function<void(int64_t, int64_t, int)> *fn; int64_t b, e; int t; ForkJoin *call; };
+struct WorkerPool {
+    std::mutex mu;
+    std::condition_variable work, done;
+    std::deque<PoolTask> q;
+    int workers = 0;
+};
+WorkerPool *g_pool = nullptr;                       // leaked on purpose: the workers sleep on it until the process ends
+std::once_flag g_pool_once;
+
+void run_task(const PoolTask &k)
+{
+    // An exception leaving a thread ends the process (std::terminate): a piece that runs out of memory hands its exception to
+    // the calling thread instead, which rethrows it once every piece is done -- the C ABI's entry points then turn it into
+    // VBNMF_ERR_OOM like any other allocation failure.
+    try {
+        (*k.fn)(k.b, k.e, k.t);
+    } catch (...) {
+        std::lock_guard<std::mutex> g(k.call->first_mu);
+        if (!k.call->first) k.call->first = std::current_exception();
+    }
+}
+
+void worker_main(WorkerPool *P)
+{
+    std::unique_lock<std::mutex> lk(P->mu);
+    for (;;) {
+        P->work.wait(lk, [&] { return !P->q.empty(); });
+        const PoolTask k = P->q.front();
+        P->q.pop_front();
+        lk.unlock();
+        run_task(k);
+        lk.lock();
+        k.call->left.fetch_sub(1, std::memory_order_acq_rel);       // (under the lock: the caller tests it under the lock as well)
+        P->done.notify_all();
+    }
+}
+
+void pool_after_fork_in_child()
+{
+    // the child has this thread only: a fresh pool (the parent's mutex may have been held by a thread that does not exist here)
+    g_pool = new WorkerPool();
+}
+
+WorkerPool *pool()
+{
+    std::call_once(g_pool_once, [] {
+        g_pool = new WorkerPool();
+        (void)pthread_atfork(nullptr, nullptr, pool_after_fork_in_child);
+    });
+    return g_pool;
+}
+}  // namespace
+
 void parallel_for(int64_t count, const std::function<void(int64_t, int64_t, int)> &fn, int max_threads)
 {
     if (count <= 0) return;
     int nt = max_threads > 0 ? max_threads : host_threads();
     if ((int64_t)nt > count) nt = (int)count;
     if (nt <= 1) { fn(0, count, 0); return; }
-    // An exception leaving a std::thread ends the process (std::terminate): a worker that runs out of memory hands its
-    // exception to the calling thread instead, which rethrows it once every worker has been joined -- the C ABI's entry
-    // points then turn it into VBNMF_ERR_OOM like any other allocation failure.
-    std::exception_ptr first;
-    std::mutex first_mu;
-    auto guarded = [&](int64_t b, int64_t e, int t) {
-        try {
-            fn(b, e, t);
-        } catch (...) {
-            std::lock_guard<std::mutex> g(first_mu);
-            if (!first) first = std::current_exception();
-        }
-    };
-    std::vector<std::thread> th;
-    th.reserve(nt);
-    for (int t = 0; t < nt; t++) {
-        int64_t b = count * t / nt, e = count * (t + 1) / nt;
-        try {
-            th.emplace_back([&guarded, b, e, t] { guarded(b, e, t); });
-        } catch (const std::system_error &) {            // thread limit reached: this piece runs here
-            guarded(b, e, t);
+    WorkerPool *P = pool();
+    ForkJoin call;
+    call.left.store(nt - 1, std::memory_order_relaxed);
+    std::vector<PoolTask> mine;                              // (built before anything is shared: an allocation failure here unwinds cleanly)
+    mine.reserve((size_t)nt - 1);
+    for (int t = 1; t < nt; t++) mine.push_back(PoolTask{&fn, count * t / nt, count * (t + 1) / nt, t, &call});
+    {
+        std::lock_guard<std::mutex> g(P->mu);
+        P->q.insert(P->q.end(), mine.begin(), mine.end());   // (at the end of a deque: all or nothing)
+        // as many workers as the widest call so far wants beside its caller (vbnmf_set_host_threads may lift the count later)
+        while (P->workers < nt - 1) {
+            try {
+                std::thread(worker_main, P).detach();
+                P->workers++;
+            } catch (const std::system_error &) {            // thread limit reached: the callers work the queue off themselves
+                break;
+            }
         }
     }
-    for (auto &x : th) x.join();
-    if (first) std::rethrow_exception(first);
+    P->work.notify_all();
+    run_task(PoolTask{&fn, 0, count / nt, 0, &call});
+    {
+        std::unique_lock<std::mutex> lk(P->mu);
+        while (call.left.load(std::memory_order_acquire) > 0) {
+            if (!P->q.empty()) {                             // help: any queued piece, this call's or not
+                const PoolTask k = P->q.front();
+                P->q.pop_front();
+                lk.unlock();
+                run_task(k);
+                lk.lock();
+                k.call->left.fetch_sub(1, std::memory_order_acq_rel);
+                P->done.notify_all();
+            } else {
+                P->done.wait(lk);
+            }
+        }
+    }
+    if (call.first) std::rethrow_exception(call.first);
 }
 
 // ------------------------------------------------------------------ ingestion

@@ -126,38 +126,75 @@ MASK = (1 << 64) - 1
 
 
 def _chunk_digest(words, seed, c=0):
-    """ccfindr_amd/csrc/engine.hip hash_bytes, one chunk of whole 8-byte words."""
-    h = (seed ^ 0x9E3779B97F4A7C15 ^ ((c * 0xD6E8FEB86659FD93) & MASK)) & MASK
+    """ccfindr_amd/csrc/engine.hip hash_bytes2, one chunk of whole 8-byte words: four chains, word q feeds chain q mod 4 (a
+    last incomplete group of words feeds chains 0, 1, ... in order), the chains combined in order.  Returns the digest and,
+    per word, the state of ITS chain before the word entered."""
+    K, KL, KC = 0xFF51AFD7ED558CCD, 0xA24BAED4963EE407, 0xC4CEB9FE1A85EC53
+    salt = 0x9E3779B97F4A7C15 ^ ((c * 0xD6E8FEB86659FD93) & MASK)
+    h = [(seed ^ salt ^ ((j * KL) & MASK)) & MASK for j in range(4)]
     trace = []
-    for w in words:
-        trace.append(h)
-        h = ((h ^ w) * 0xFF51AFD7ED558CCD) & MASK
-        h ^= h >> 32
-    return h, trace
+    for q, w in enumerate(words):
+        j = q % 4
+        trace.append(h[j])
+        h[j] = ((h[j] ^ w) * K) & MASK
+        h[j] ^= h[j] >> 32
+    d = h[0]
+    for j in range(1, 4):
+        d = ((d ^ h[j]) * KC) & MASK
+        d ^= d >> 29
+    return d, trace
+
+
+def _whole_hash(words, seed):
+    d, _ = _chunk_digest(words, seed)
+    h = ((seed ^ d) * 0xC4CEB9FE1A85EC53) & MASK
+    return h ^ (h >> 29)
 
 
 def test_two_seeds_give_independent_hashes():
-    """Two buffers built to collide in their chunk digest under seed A (the second word of the second buffer cancels the
-    state difference the first word made) hash alike under A and differently under B: the key is 128 bits, not 64."""
+    """Two buffers built to collide in one chain under seed A (a later word of the same chain cancels the state difference an
+    earlier word made) hash alike under A and differently under B: the key is 128 bits, not 64.  Also pins the function
+    itself against the model above (the value must not depend on the library's thread count or build)."""
     from ccfindr_amd import _native as N
     L = N.load()
     A, B = 0x64656E7365, 0x3243F6A8885A308D
     rng = np.random.default_rng(5)
-    w = [int(v) for v in rng.integers(0, 1 << 63, size=6, dtype=np.int64)]
+    w = [int(v) for v in rng.integers(0, 1 << 63, size=11, dtype=np.int64)]
     v = list(w)
-    v[2] ^= 0x5DEECE66D                                                  # differ at word 2 ...
-    _, tw = _chunk_digest(w[:4], A)
-    _, tv = _chunk_digest(v[:4], A)
-    v[3] = w[3] ^ tw[3] ^ tv[3]                                          # ... and cancel the state difference at word 3
+    v[2] ^= 0x5DEECE66D                                                  # differ at word 2 (chain 2) ...
+    _, tw = _chunk_digest(w[:7], A)
+    _, tv = _chunk_digest(v[:7], A)
+    v[6] = w[6] ^ tw[6] ^ tv[6]                                          # ... and cancel the state difference at word 6, same chain
     assert _chunk_digest(w, A)[0] == _chunk_digest(v, A)[0] and w != v
 
     def lib_hash(words, seed):
         buf = np.asarray(words, dtype=np.uint64)
         return int(L.vbnmf_test_hash_bytes(buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes, seed))
 
+    assert lib_hash(w, A) == _whole_hash(w, A) and lib_hash(w, B) == _whole_hash(w, B)     # the library computes the model
     assert lib_hash(w, A) == lib_hash(v, A)                              # the constructed collision is real ...
     assert lib_hash(w, B) != lib_hash(v, B)                              # ... and the second seed tells the buffers apart
     assert lib_hash(w, A) != lib_hash(w, B)
+
+
+def test_hash_does_not_depend_on_the_thread_count():
+    """Chunks (4 MB) are hashed by whatever threads there are and combined in order."""
+    from ccfindr_amd import _native as N
+    from ccfindr_amd.engine import host_threads, set_host_threads
+    L = N.load()
+    rng = np.random.default_rng(8)
+    buf = rng.integers(0, 255, size=(9 << 20) + 13, dtype=np.uint8)      # three chunks, the last ragged, a byte tail
+    got = []
+    try:
+        for nt in (1, 2, 7):
+            set_host_threads(nt)
+            assert host_threads() == nt
+            got.append(int(L.vbnmf_test_hash_bytes(buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes, 77)))
+    finally:
+        set_host_threads(0)
+    assert got[0] == got[1] == got[2]
+    buf[5 << 20] ^= 1
+    assert int(L.vbnmf_test_hash_bytes(buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes, 77)) != got[0]
 
 
 @pytest.mark.parametrize("wide", [False, True])
