@@ -24,12 +24,25 @@ void parallel_for(int64_t count, const std::function<void(int64_t begin, int64_t
                   int max_threads = 0);
 int host_threads();
 void set_host_threads_override(int n);      // 0: back to the default rule (cores of the affinity mask, at most 32)
+void set_thread_share(int share);           // the CALLING thread's parallel_for calls default to host_threads() / share threads (1: all)
 
 // The same matrix by rows (genes), columns ascending in each row: what the gene side of the layout is cut from.
+// std::allocator whose resize() leaves trivially constructible elements uninitialised (no zero-fill pass over the
+// 200 MB entry arrays: the builder writes every slot itself, and the pages are first touched by the threads that fill them).
+template <class T>
+struct NoInitAlloc : std::allocator<T> {
+    template <class U> struct rebind { using other = NoInitAlloc<U>; };
+    NoInitAlloc() = default;
+    template <class U> NoInitAlloc(const NoInitAlloc<U> &) {}
+    template <class U> void construct(U *p) noexcept { ::new (static_cast<void *>(p)) U; }
+    template <class U, class... A> void construct(U *p, A &&...a) { ::new (static_cast<void *>(p)) U(std::forward<A>(a)...); }
+};
+template <class T> using BigVec = std::vector<T, NoInitAlloc<T>>;
+
 struct RowMajor {
     std::vector<int64_t> ptr;      // n+1
-    std::vector<int32_t> idx;      // nnz
-    std::vector<double> val;       // nnz
+    BigVec<int32_t> idx;           // nnz
+    BigVec<double> val;            // nnz
 };
 struct RowMajorCache {
     std::once_flag once;
@@ -87,18 +100,6 @@ constexpr uint32_t kIdleLane = 0xFFFFFFFFu;
 constexpr int kPackedCountShift = 18;
 constexpr uint32_t kPackedOffsetMask = 0x3FFF0u;
 constexpr double kPackedCountMax = 16383.0;
-
-// std::allocator whose resize() leaves trivially constructible elements uninitialised (no zero-fill pass over the
-// 200 MB entry arrays: the builder writes every slot itself).
-template <class T>
-struct NoInitAlloc : std::allocator<T> {
-    template <class U> struct rebind { using other = NoInitAlloc<U>; };
-    NoInitAlloc() = default;
-    template <class U> NoInitAlloc(const NoInitAlloc<U> &) {}
-    template <class U> void construct(U *p) noexcept { ::new (static_cast<void *>(p)) U; }
-    template <class U, class... A> void construct(U *p, A &&...a) { ::new (static_cast<void *>(p)) U(std::forward<A>(a)...); }
-};
-template <class T> using BigVec = std::vector<T, NoInitAlloc<T>>;
 
 // The big arrays of a layout (the packed entry stream: 200 MB a side at the headline size) live either in the library's
 // own memory or INSIDE a shared-memory segment mapped by every process of the node (vbnmf_matrix_share_layout /
@@ -213,11 +214,6 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
 std::vector<int32_t> compute_cell_order(const Matrix &X, int64_t cb, int64_t ce);
 
 const char *last_error_cstr();
-
-// perm (optional, nouter entries): outer vector p of the result's numbering is input vector perm[p]
-void transpose_compressed(int64_t nouter, int64_t ninner, const int64_t *ptr, const int32_t *idx, const double *val,
-                          int32_t idx_offset, std::vector<int64_t> &tptr, std::vector<int32_t> &tidx, std::vector<double> &tval,
-                          const int32_t *perm = nullptr);
 
 // Canonical matrix from compressed columns in any order within a column (duplicates summed, zeros dropped).
 int matrix_from_csc(int64_t n, int64_t m, const int32_t *p, const int32_t *i, const double *x, Matrix &X);

@@ -1014,6 +1014,12 @@ int vbnmf_engine_create_geom(const vbnmf_matrix *X, int64_t cb, int64_t ce, int6
 
     vbnmf_engine *e = new (std::nothrow) vbnmf_engine();
     if (!e) return fail(VBNMF_ERR_OOM, "out of host memory");
+    // VBNMF_BUILD_TIMES=1: where the seconds of this creation go (offsets from here; the layouts' own phases come from host.cpp)
+    const bool tl_on = getenv("VBNMF_BUILD_TIMES") != nullptr;
+    const auto tl_0 = std::chrono::steady_clock::now();
+    auto mark = [&](const char *what) {
+        if (tl_on) fprintf(stderr, "  engine create +%.3f s  %s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - tl_0).count(), what);
+    };
     e->device = device;
     e->n = X->M.n; e->m = ce - cb; e->m_global = m_global; e->col_begin = cb;
     e->r = r; e->R = padded_rank(r);
@@ -1057,7 +1063,9 @@ int vbnmf_engine_create_geom(const vbnmf_matrix *X, int64_t cb, int64_t ce, int6
         // thread, the gene side here.  Each cut is memory-bound well before it uses all host threads, and a side's upload
         // (200 MB of pageable memory at the headline size) runs beside the other side's cut.  Engine creation at the headline
         // size: 0.41 -> 0.3 s on the GPU box (profiles/r05_setup_times.txt).  VBNMF_SERIAL_SIDES=1: one after the other.
+        mark("stream, workgroups");
         if (cb == 0 && ce == X->M.m && !X->M.shell) (void)X->M.cell_order();          // (both sides start from it: formed once, here)
+        mark("cell order");
         auto do_side = [&](int side) -> int {
             int src = VBNMF_OK;
             const int64_t nmaj = side == 0 ? e->n : e->m, nmin = side == 0 ? e->m : e->n;
@@ -1075,7 +1083,9 @@ int vbnmf_engine_create_geom(const vbnmf_matrix *X, int64_t cb, int64_t ce, int6
             } else {
                 src = build_layout(X->M, cb, ce, side, lp, &part_order, own);
             }
+            mark(side == 0 ? "gene side cut" : "cell side cut");
             if (!src) src = upload_side(*L, e->R, device, shared ? X : nullptr, side == 0 ? e->A : e->B);
+            mark(side == 0 ? "gene side uploaded" : "cell side uploaded");
             Ls[side] = L;
             return src;
         };
@@ -1087,14 +1097,18 @@ int vbnmf_engine_create_geom(const vbnmf_matrix *X, int64_t cb, int64_t ce, int6
             rc = do_side(0);
             if (!rc) rc = do_side(1);
         } else {
+            static const int side_share = [] { const char *v = getenv("VBNMF_SIDE_THREAD_SHARE"); return v ? std::max(1, atoi(v)) : 1; }();
             std::thread cell_side([&] {
                 try {
                     if (hipSetDevice(device) != hipSuccess) { rc1 = VBNMF_ERR_HIP; msg1 = "hipSetDevice failed on the layout thread"; return; }
+                    set_thread_share(side_share);
                     rc1 = do_side(1);
                     if (rc1) msg1 = last_error_cstr();               // (error messages are per host thread)
                 } catch (const std::bad_alloc &) { oom1 = true; }
             });
-            try { rc = do_side(0); } catch (...) { cell_side.join(); throw; }
+            set_thread_share(side_share);
+            try { rc = do_side(0); } catch (...) { set_thread_share(1); cell_side.join(); throw; }
+            set_thread_share(1);
             cell_side.join();
             if (oom1) throw std::bad_alloc();
             if (!rc && rc1) rc = fail(rc1, "%s", msg1.c_str());
@@ -1128,6 +1142,7 @@ int vbnmf_engine_create_geom(const vbnmf_matrix *X, int64_t cb, int64_t ce, int6
         rc = fail(VBNMF_ERR_OOM, "out of host memory building the tiled layout");
     }
     if (rc) return bail(rc);
+    mark("both sides, update table");
     if (!e->cell_perm.empty() && (rc = dev_upload(&e->d_perm, e->cell_perm))) return bail(rc);
     e->lgx = (cb == 0 && ce == X->M.m) ? X->lgx : sum_lgamma_x1(X->M, cb, ce);
     if (cb == 0 && ce == X->M.m) {                    // whole matrix: formed once per matrix, not per engine (a pass over X)
@@ -1148,6 +1163,7 @@ int vbnmf_engine_create_geom(const vbnmf_matrix *X, int64_t cb, int64_t ce, int6
         e->stream_nt = moved > 200e6;
         if (const char *v = getenv("VBNMF_STREAM_NT")) e->stream_nt = v[0] == '1';
     }
+    mark("sum x log x");
     static_assert(kLdsRowBase == kLdsReserveBytes, "host and device disagree on the sweep's LDS reserve");
     e->lds_bytes = kLdsRowBase + std::max((size_t)e->A.block_width * e->A.row_slots, (size_t)e->B.block_width * e->B.row_slots) * 16;
     if (e->lds_bytes > 160 * 1024) return bail(fail(VBNMF_ERR_BAD_ARG, "the layout's blocks need %zu bytes of LDS", e->lds_bytes));
@@ -1201,6 +1217,7 @@ int vbnmf_engine_create_geom(const vbnmf_matrix *X, int64_t cb, int64_t ce, int6
         return bail(fail(VBNMF_ERR_HIP, "hipMemcpyAsync failed: %s", hipGetErrorString(he)));
     // creation ends with the engine's buffers in their initial state whatever else the device is doing
     if ((he = hipStreamSynchronize(e->stream)) != hipSuccess) return bail(fail(VBNMF_ERR_HIP, "engine setup failed: %s", hipGetErrorString(he)));
+    mark("state arrays, initial fills, done");
     *out = e;
     return VBNMF_OK;
 }

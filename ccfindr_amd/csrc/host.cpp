@@ -17,9 +17,6 @@
 #include <unistd.h>
 
 #include <chrono>
-#include <condition_variable>
-#include <deque>
-#include <pthread.h>
 #include <system_error>
 #include <cmath>
 #include <cstdlib>
@@ -78,118 +75,49 @@ int host_threads()
     return n;
 }
 
-// Fork-join over [0, count) on a pool of worker threads that outlives the call.  (Until round 5 every call started and joined its
-// own std::threads: ~25 us apiece, i.e. the better part of a millisecond per call on 32 threads -- more than the work itself in
-// the state conversions of set_state / get_state, 3 + 5 ms of every literal drop-in call on a 2 000 x 5 000 matrix, and several
-// dozen times per layout.)  The pieces of a call are the same whatever runs them: piece t covers [count t / nt, count (t+1) / nt)
-// and is handed t as its `tid`, so results that depend on the split (none should; tests/test_node_shared_cpu.py) do not change.
-// The caller runs piece 0 itself and then HELPS: while its call is unfinished it takes queued pieces -- its own or another
-// caller's (engine creation cuts two layouts on two host threads; a piece may itself call parallel_for) -- so a call completes
-// even with no worker at all (thread limit reached; the child of a fork, which inherits the queue's bookkeeping but no threads).
-namespace {
-struct ForkJoin {                                   // one call
-    std::atomic<int> left{0};
-    std::exception_ptr first;
-    std::mutex first_mu;
-};
-struct PoolTask { const std::function<void(int64_t, int64_t, int)> *fn; int64_t b, e; int t; ForkJoin *call; };
-struct WorkerPool {
-    std::mutex mu;
-    std::condition_variable work, done;
-    std::deque<PoolTask> q;
-    int workers = 0;
-};
-WorkerPool *g_pool = nullptr;                       // leaked on purpose: the workers sleep on it until the process ends
-std::once_flag g_pool_once;
-
-void run_task(const PoolTask &k)
-{
-    // An exception leaving a thread ends the process (std::terminate): a piece that runs out of memory hands its exception to
-    // the calling thread instead, which rethrows it once every piece is done -- the C ABI's entry points then turn it into
-    // VBNMF_ERR_OOM like any other allocation failure.
-    try {
-        (*k.fn)(k.b, k.e, k.t);
-    } catch (...) {
-        std::lock_guard<std::mutex> g(k.call->first_mu);
-        if (!k.call->first) k.call->first = std::current_exception();
-    }
-}
-
-void worker_main(WorkerPool *P)
-{
-    std::unique_lock<std::mutex> lk(P->mu);
-    for (;;) {
-        P->work.wait(lk, [&] { return !P->q.empty(); });
-        const PoolTask k = P->q.front();
-        P->q.pop_front();
-        lk.unlock();
-        run_task(k);
-        lk.lock();
-        k.call->left.fetch_sub(1, std::memory_order_acq_rel);       // (under the lock: the caller tests it under the lock as well)
-        P->done.notify_all();
-    }
-}
-
-void pool_after_fork_in_child()
-{
-    // the child has this thread only: a fresh pool (the parent's mutex may have been held by a thread that does not exist here)
-    g_pool = new WorkerPool();
-}
-
-WorkerPool *pool()
-{
-    std::call_once(g_pool_once, [] {
-        g_pool = new WorkerPool();
-        (void)pthread_atfork(nullptr, nullptr, pool_after_fork_in_child);
-    });
-    return g_pool;
-}
-}  // namespace
+// Fork-join over [0, count): every call starts and joins its own threads (~25 us apiece on the GPU box's host).  Round 5 built
+// the alternative -- a pool of workers that outlives the call, the caller helping -- and measured it on the headline matrix's
+// set-up (profiles/r05_setup_pool_ab.txt, r05_transpose_ab2.txt): the dispatch is cheaper, but the heavy phases run SLOWER on
+// woken workers than on fresh threads (the fill of the gene side 0.07-0.09 s against 0.04-0.05 s, engine creation 0.30-0.36 s
+// against 0.25-0.28 s): a new thread is placed on the idlest core of a 256-CPU host, a woken one near where it last ran or near
+// its waker, and a phase of 40 ms is over before the balancer has spread them.  So: threads per call, and callers whose work is
+// small ask for few of them (the state conversions of set_state / get_state, the cache key of the stateless entries).
+static thread_local int tl_thread_share = 1;          // this host thread's calls use host_threads() / share threads by default
+void set_thread_share(int share) { tl_thread_share = share > 1 ? share : 1; }
+static int default_threads() { return std::max(1, host_threads() / tl_thread_share); }
 
 void parallel_for(int64_t count, const std::function<void(int64_t, int64_t, int)> &fn, int max_threads)
 {
     if (count <= 0) return;
-    int nt = max_threads > 0 ? max_threads : host_threads();
+    int nt = max_threads > 0 ? max_threads : default_threads();
     if ((int64_t)nt > count) nt = (int)count;
     if (nt <= 1) { fn(0, count, 0); return; }
-    WorkerPool *P = pool();
-    ForkJoin call;
-    call.left.store(nt - 1, std::memory_order_relaxed);
-    std::vector<PoolTask> mine;                              // (built before anything is shared: an allocation failure here unwinds cleanly)
-    mine.reserve((size_t)nt - 1);
-    for (int t = 1; t < nt; t++) mine.push_back(PoolTask{&fn, count * t / nt, count * (t + 1) / nt, t, &call});
-    {
-        std::lock_guard<std::mutex> g(P->mu);
-        P->q.insert(P->q.end(), mine.begin(), mine.end());   // (at the end of a deque: all or nothing)
-        // as many workers as the widest call so far wants beside its caller (vbnmf_set_host_threads may lift the count later)
-        while (P->workers < nt - 1) {
-            try {
-                std::thread(worker_main, P).detach();
-                P->workers++;
-            } catch (const std::system_error &) {            // thread limit reached: the callers work the queue off themselves
-                break;
-            }
+    // An exception leaving a std::thread ends the process (std::terminate): a worker that runs out of memory hands its
+    // exception to the calling thread instead, which rethrows it once every worker has been joined -- the C ABI's entry
+    // points then turn it into VBNMF_ERR_OOM like any other allocation failure.
+    std::exception_ptr first;
+    std::mutex first_mu;
+    auto guarded = [&](int64_t b, int64_t e, int t) {
+        try {
+            fn(b, e, t);
+        } catch (...) {
+            std::lock_guard<std::mutex> g(first_mu);
+            if (!first) first = std::current_exception();
+        }
+    };
+    std::vector<std::thread> th;
+    th.reserve(nt);
+    for (int t = 1; t < nt; t++) {
+        int64_t b = count * t / nt, e = count * (t + 1) / nt;
+        try {
+            th.emplace_back([&guarded, b, e, t] { guarded(b, e, t); });
+        } catch (const std::system_error &) {            // thread limit reached: this piece runs here
+            guarded(b, e, t);
         }
     }
-    P->work.notify_all();
-    run_task(PoolTask{&fn, 0, count / nt, 0, &call});
-    {
-        std::unique_lock<std::mutex> lk(P->mu);
-        while (call.left.load(std::memory_order_acquire) > 0) {
-            if (!P->q.empty()) {                             // help: any queued piece, this call's or not
-                const PoolTask k = P->q.front();
-                P->q.pop_front();
-                lk.unlock();
-                run_task(k);
-                lk.lock();
-                k.call->left.fetch_sub(1, std::memory_order_acq_rel);
-                P->done.notify_all();
-            } else {
-                P->done.wait(lk);
-            }
-        }
-    }
-    if (call.first) std::rethrow_exception(call.first);
+    guarded(0, count / nt, 0);                           // (the caller takes the first piece instead of sleeping)
+    for (auto &x : th) x.join();
+    if (first) std::rethrow_exception(first);
 }
 
 // ------------------------------------------------------------------ ingestion
@@ -217,6 +145,10 @@ static void finish_matrix(Matrix &X)
     X.max_val = mx;
     X.counts_u16 = ints && mx <= kPackedCountMax;
 }
+
+template <class VI, class VD>
+static void transpose_compressed(int64_t nouter, int64_t ninner, const int64_t *ptr, const int32_t *idx, const double *val,
+                                 int32_t idx_offset, std::vector<int64_t> &tptr, VI &tidx, VD &tval, const int32_t *perm);
 
 const RowMajor &Matrix::row_major() const
 {
@@ -332,49 +264,94 @@ int matrix_from_csc(int64_t n, int64_t m, const int32_t *p, const int32_t *i, co
 }
 
 // Transpose a canonical compressed matrix (nouter x ninner) into the other orientation (inner indices of the
-// result ascending).  Outer vectors are cut into one chunk per thread; each chunk counts its entries per inner
-// index, an exclusive scan over (inner index, chunk) gives every chunk its write positions, then the chunks scatter.
-// (Round 5 measured a two-level form -- entries first into <= 256 buckets of consecutive inner indices as 16-byte records,
-// then a stable pass inside every bucket -- against this one-level scatter on the GPU box's host, 4.9e7 entries:
-// 0.27 s against 0.117 s.  The record buffer's fresh 800 MB cost more than the scattered cursors; kept: this form.)
-void transpose_compressed(int64_t nouter, int64_t ninner, const int64_t *ptr, const int32_t *idx, const double *val,
-                          int32_t idx_offset, std::vector<int64_t> &tptr, std::vector<int32_t> &tidx, std::vector<double> &tval,
-                          const int32_t *perm)
+// result ascending).  The OUTPUT is what the threads divide: the inner indices are cut into ranges (a few hundred rows of the
+// result each), and since every outer vector holds its inner indices in ascending order, the stretch of it that falls into a
+// range is found by bisection (a table of nouter x (ranges + 1) offsets, one pass).  A thread then takes a range: it counts the
+// range's entries per inner index, scans, and scatters them -- outer vectors in order, so the result is ascending -- with all its
+// write cursors (a few hundred) and its output stretch in its own cache.  The earlier form divided the INPUT (one chunk of outer
+// vectors per thread, a counter per (chunk, inner index), every thread scattering into all 20 000 rows of the result): 0.117 s
+// for the headline matrix's 4.9e7 entries on the GPU box's host, most of it cache misses of the scatter; this one 0.06-0.08 s
+// (profiles/r05_transpose_ab2.txt).  Round 5 also measured a two-level form (entries first into <= 256 buckets as 16-byte records,
+// then a stable pass inside every bucket): 0.27 s -- the record buffer's fresh 800 MB cost more than the scattered cursors.
+// The result does not depend on the thread count (each range's content and order are fixed by the input alone).
+// perm (optional, nouter entries): outer vector p of the result's numbering is input vector perm[p].  VI / VD: vectors of
+// int32_t / double (BigVec where the caller can take it: the 600 MB of the result are then first touched by the threads that
+// write them instead of being zero-filled by the caller's one).
+template <class VI, class VD>
+static void transpose_compressed(int64_t nouter, int64_t ninner, const int64_t *ptr, const int32_t *idx, const double *val,
+                                 int32_t idx_offset, std::vector<int64_t> &tptr, VI &tidx, VD &tval, const int32_t *perm)
 {
     const int64_t s = ptr[0], t = ptr[nouter];
-    int T = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), (t - s) / (1 << 18) + 1));
-    while (T > 1 && (int64_t)T * ninner > (int64_t)1 << 28) T /= 2;             // cap the counter table at 2 GiB
-    std::vector<int64_t> cut(T + 1);
-    for (int c = 0; c <= T; c++) cut[c] = nouter * c / T;
+    const auto t_0 = std::chrono::steady_clock::now();
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(default_threads(), (t - s) / (1 << 18) + 1));
     auto src = [&](int64_t j) { return perm ? (int64_t)perm[j] : j; };          // input vector stored at position j
-    std::vector<int64_t> cnt((size_t)T * ninner, 0);
-    parallel_for(T, [&](int64_t b, int64_t e, int) {
-        for (int64_t c = b; c < e; c++) {
-            int64_t *my = &cnt[(size_t)c * ninner];
-            for (int64_t j = cut[c]; j < cut[c + 1]; j++)
-                for (int64_t q = ptr[src(j)]; q < ptr[src(j) + 1]; q++) my[idx[q]]++;
-        }
-    }, T);
     tptr.assign(ninner + 1, 0);
-    int64_t run = 0;
-    for (int64_t i = 0; i < ninner; i++) {
-        tptr[i] = run;
-        for (int c = 0; c < T; c++) { const int64_t k = cnt[(size_t)c * ninner + i]; cnt[(size_t)c * ninner + i] = run; run += k; }
-    }
-    tptr[ninner] = run;
     tidx.resize(t - s);
     tval.resize(t - s);
-    parallel_for(T, [&](int64_t b, int64_t e, int) {
-        for (int64_t c = b; c < e; c++) {
-            int64_t *cur = &cnt[(size_t)c * ninner];
-            for (int64_t j = cut[c]; j < cut[c + 1]; j++)
-                for (int64_t q = ptr[src(j)]; q < ptr[src(j) + 1]; q++) {
-                    const int64_t o = cur[idx[q]]++;
-                    tidx[o] = (int32_t)(j - idx_offset);
-                    tval[o] = val[q];
-                }
+    if (ninner <= 0) return;
+    // ranges of inner indices: a few per thread (they differ in entries; handed out through a counter), one when serial
+    int64_t G = T == 1 ? 1 : std::min<int64_t>(ninner, 4 * (int64_t)T);
+    while (G > 1 && nouter * (G + 1) > ((int64_t)1 << 26)) G /= 2;                 // (the table of offsets below: at most 256 MB)
+    auto lo_of = [&](int64_t g) { return ninner * g / G; };
+    // split[j * (G + 1) + g]: offset inside outer vector j (position order) of its first entry with inner index >= lo_of(g)
+    std::vector<uint32_t> split((size_t)nouter * (size_t)(G + 1));
+    std::vector<int64_t> tot_t((size_t)T * (size_t)G, 0);                       // entries per range, by thread
+    parallel_for(nouter, [&](int64_t b, int64_t e, int tid) {
+        int64_t *tot = &tot_t[(size_t)tid * (size_t)G];
+        for (int64_t j = b; j < e; j++) {
+            const int64_t c = src(j);
+            const int32_t *first = idx + ptr[c], *last = idx + ptr[c + 1];
+            uint32_t *sp = &split[(size_t)j * (size_t)(G + 1)];
+            const int32_t *at = first;
+            sp[0] = 0;
+            for (int64_t g = 1; g < G; g++) {
+                at = std::lower_bound(at, last, (int32_t)lo_of(g));
+                sp[g] = (uint32_t)(at - first);
+                tot[g - 1] += (int64_t)sp[g] - (int64_t)sp[g - 1];
+            }
+            sp[G] = (uint32_t)(last - first);
+            tot[G - 1] += (int64_t)sp[G] - (int64_t)sp[G - 1];
         }
     }, T);
+    static const bool tt = getenv("VBNMF_BUILD_TIMES") != nullptr;
+    auto t_a = std::chrono::steady_clock::now();
+    std::vector<int64_t> base((size_t)G + 1, 0);
+    for (int64_t g = 0; g < G; g++) {
+        int64_t k = 0;
+        for (int c = 0; c < T; c++) k += tot_t[(size_t)c * (size_t)G + (size_t)g];
+        base[g + 1] = base[g] + k;
+    }
+    std::atomic<int64_t> next{0};
+    parallel_for(T, [&](int64_t, int64_t, int) {
+        std::vector<int64_t> cur;
+        for (;;) {
+            const int64_t g = next.fetch_add(1);
+            if (g >= G) break;
+            const int64_t lo = lo_of(g), hi = lo_of(g + 1);
+            cur.assign((size_t)(hi - lo) + 1, 0);
+            for (int64_t j = 0; j < nouter; j++) {
+                const uint32_t *sp = &split[(size_t)j * (size_t)(G + 1) + (size_t)g];
+                const int32_t *q = idx + ptr[src(j)];
+                for (uint32_t u = sp[0]; u < sp[1]; u++) cur[(size_t)(q[u] - lo) + 1]++;
+            }
+            int64_t run = base[g];
+            for (int64_t i = 0; i < hi - lo; i++) { const int64_t k = cur[(size_t)i + 1]; tptr[lo + i] = run; cur[(size_t)i] = run; run += k; }
+            for (int64_t j = 0; j < nouter; j++) {
+                const uint32_t *sp = &split[(size_t)j * (size_t)(G + 1) + (size_t)g];
+                const int64_t c0 = ptr[src(j)];
+                const int32_t *q = idx + c0;
+                const double *v = val + c0;
+                for (uint32_t u = sp[0]; u < sp[1]; u++) {
+                    const int64_t o = cur[(size_t)(q[u] - lo)]++;
+                    tidx[o] = (int32_t)(j - idx_offset);
+                    tval[o] = v[u];
+                }
+            }
+        }
+    }, T);
+    tptr[ninner] = t - s;
+    if (tt) fprintf(stderr, "  transpose: T %d, G %lld, after the split table %.4f s, ranges %.4f s\n", T, (long long)G,
+                    std::chrono::duration<double>(t_a - t_0).count(), std::chrono::duration<double>(std::chrono::steady_clock::now() - t_a).count());
 }
 
 static int matrix_from_csr(int64_t n, int64_t m, const int32_t *p, const int32_t *j, const double *x, Matrix &X)
@@ -385,7 +362,7 @@ static int matrix_from_csr(int64_t n, int64_t m, const int32_t *p, const int32_t
     int rc = canonicalise(n, m, p, j, x, rptr, ridx, rval);
     if (rc) return rc;
     X.n = n; X.m = m;
-    transpose_compressed(n, m, rptr.data(), ridx.data(), rval.data(), 0, X.colptr, X.row, X.val);
+    transpose_compressed(n, m, rptr.data(), ridx.data(), rval.data(), 0, X.colptr, X.row, X.val, nullptr);
     finish_matrix(X);
     return VBNMF_OK;
 }
@@ -510,8 +487,8 @@ int build_layout(const Matrix &X, int64_t cb, int64_t ce, int side, const Layout
     auto lap = [&](const char *what) { if (getenv("VBNMF_BUILD_TIMES")) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "  layout side %d %-12s %.3f s\n", side, what, std::chrono::duration<double>(t - T0).count()); T0 = t; } };
     // major-compressed view of X[:, cb:ce)
     std::vector<int64_t> tptr;
-    std::vector<int32_t> tidx;
-    std::vector<double> tval;
+    BigVec<int32_t> tidx;
+    BigVec<double> tval;
     // entries of major M: [pb[M], pe[M]) of idx / val.  Contiguous majors: pb = ptr, pe = ptr + 1; the cell side under a
     // renumbering of the cells walks the columns in the new order through two index arrays instead (no copy of X).
     const int64_t *pb, *pe;

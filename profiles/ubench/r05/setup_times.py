@@ -24,3 +24,4 @@ for rep in range(2):
     for tag, env in (("sides side by side", {}), ("sides one after the other", {"VBNMF_SERIAL_SIDES": "1"})):
         subprocess.run([sys.executable, os.path.abspath(__file__), tag], env=dict(os.environ, **env), check=True)
 subprocess.run([sys.executable, os.path.abspath(__file__), "phases (serial)"], env=dict(os.environ, VBNMF_SERIAL_SIDES="1", VBNMF_BUILD_TIMES="1"), check=True)
+subprocess.run([sys.executable, os.path.abspath(__file__), "phases (side by side)"], env=dict(os.environ, VBNMF_BUILD_TIMES="1"), check=True)
