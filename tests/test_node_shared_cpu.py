@@ -259,6 +259,48 @@ def test_layouts_do_not_depend_on_the_host_thread_count():
         assert blobs[nt][0] == blobs[1][0] and blobs[nt][1] == blobs[1][1], nt
 
 
+def test_row_major_copy_by_ranges_of_the_output():
+    """csrc/host.cpp transpose_compressed: from 2^18 stored entries on, several threads divide the OUTPUT into ranges of rows
+    (bisection of every sorted column, then count / scan / scatter per range).  Held against the one-thread form (one range: a
+    plain counting transposition) through both callers: the gene side's layout, cut from the row-major copy in the cells'
+    renumbered order, must be the same bytes; and a matrix ingested by rows must come back as the matrix it was."""
+    import scipy.sparse as sp
+    import ccfindr_amd as C
+    from ccfindr_amd.engine import set_host_threads
+    rng = np.random.default_rng(12)
+    n, m = 1500, 5200
+    X = sp.random(n, m, density=0.11, format="csc", random_state=rng, data_rvs=lambda k: rng.integers(1, 9, k).astype(np.float64))
+    keep_r, keep_c = np.ones(n), np.ones(m)
+    keep_r[rng.integers(0, n, 40)] = 0.0                                 # some empty genes, some empty cells, ragged ranges
+    keep_c[rng.integers(0, m, 60)] = 0.0
+    X = sp.csc_matrix(sp.diags(keep_r) @ X @ sp.diags(keep_c))
+    X.eliminate_zeros()
+    assert X.nnz > 3 * (1 << 18)
+    blobs = {}
+    try:
+        for nt in (1, 5):
+            set_host_threads(nt)
+            os.environ["VBNMF_CELL_ORDER"] = "1"                         # the copy is made in the cells' renumbered order
+            M = C.CountMatrix(X)
+            nb = M.layout_blob_size(0, 10, 256)
+            blob = bytearray(nb)
+            M.export_layout(0, 10, 256, blob)
+            blobs[nt] = bytes(blob)
+            M.close()
+            R = C.CountMatrix(X.tocsr())                                 # by rows: transposed into the canonical columns
+            back = R.to_scipy().tocsc()
+            back.sort_indices()
+            ref = X.copy()
+            ref.sort_indices()
+            assert back.shape == ref.shape and np.array_equal(back.indptr, ref.indptr)
+            assert np.array_equal(back.indices, ref.indices) and np.array_equal(back.data, ref.data)
+            R.close()
+    finally:
+        os.environ.pop("VBNMF_CELL_ORDER", None)
+        set_host_threads(0)
+    assert blobs[5] == blobs[1]
+
+
 def test_usable_cores_follows_the_affinity_mask_and_the_cgroup_quota(monkeypatch, tmp_path):
     """The layout builder of a node takes its waiting peers' cores -- as many as this process may REALLY use: the affinity mask
     cut down to the cgroup's CPU quota (round 5: 128 visible CPUs under a quota of 16 made the builder's 128 threads cut the
