@@ -52,6 +52,66 @@ def test_concurrent_units_give_the_same_result():
     M.close()
 
 
+def test_an_engine_created_while_the_null_stream_is_busy_starts_from_the_same_buffers():
+    """Engine creation zeroes its block partials, column sums and `ew / dw / dh`.  Until round 5 it did so with hipMemset, which
+    on this ROCm returns at once and runs on the device's NULL stream -- which the engine's non-blocking stream does not wait
+    for: with the null stream backed up (other host threads creating engines, vb_factorize(concurrent=K); here: a second
+    host thread queueing large fills through torch, whose default stream is the null stream) the zeros landed AFTER the priming kernels of
+    set_state had written the same buffers, and the first step started from zeroed partials.  The fills are on the engine's own
+    stream now: an engine created under that load must give the bits of one created on an idle device.  (The invariant, not a
+    reproducer: the old library passes this too on most boxes -- the failure needed several engine-creating host threads,
+    test_concurrent_units_give_the_same_result under VBNMF_HOST_THREADS=1, profiles/r05_concurrent_race.txt.)"""
+    import torch
+    import ccfindr_amd as C
+    from ccfindr_amd import synth
+    X = synth.drop_empty(synth.simulate_data(300, (120, 200), seed=4, sparse=True))
+    n, m = X.shape
+    r = 4
+    hy = {"aw": 0.9, "bw": 1.1, "ah": 1.2, "bh": 0.8}
+    wh = synth.random_state(n, m, r, hy, seed=5)
+    M = C.CountMatrix(X)
+
+    def three_steps():
+        eng = C.VBEngine(M, r)
+        eng.set_state(wh["lw"], wh["lh"], wh["eh"])
+        lk = [eng.step(hy)[0] for _ in range(3)]
+        st = eng.get_state()
+        eng.close()
+        return lk, st
+
+    import threading
+    quiet = three_steps()
+    big = torch.empty(2 << 30, dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    stop = threading.Event()
+
+    def keep_the_null_stream_busy():                             # a queue of fills, two batches (~7 ms) deep, until told to stop
+        pending = []
+        while not stop.is_set():
+            for _ in range(10):
+                big.zero_()
+            ev = torch.cuda.Event()
+            ev.record()
+            pending.append(ev)
+            if len(pending) > 2:
+                pending.pop(0).synchronize()
+        torch.cuda.synchronize()
+
+    th = threading.Thread(target=keep_the_null_stream_busy)
+    th.start()
+    try:
+        busy = [three_steps() for _ in range(3)]
+    finally:
+        stop.set()
+        th.join()
+    del big
+    for lk, st in busy:
+        assert lk == quiet[0]
+        for k in quiet[1]:
+            assert np.array_equal(st[k], quiet[1][k]), k
+    M.close()
+
+
 def test_layouts_uploaded_ahead_of_the_first_engine_change_nothing():
     """vbnmf_device_warmup / vbnmf_matrix_prepare_async / vbnmf_matrix_preload_layout only move work earlier (the sharded
     sweep's peers spend their wait for the layouts there): an engine created afterwards is bit-identical to one created cold,
