@@ -34,17 +34,25 @@ def test_files_to_clusters(tmp_path):
     M.close()
 
 
-def test_concurrent_units_give_the_same_result():
+@pytest.mark.parametrize("host_threads", [0, 1])
+def test_concurrent_units_give_the_same_result(host_threads):
     """vb_factorize(concurrent=4): (run, rank) units overlap on the one GPU; every unit has its own seeded stream, so the
-    outcome is that of the sequential driver, bit for bit."""
+    outcome is that of the sequential driver, bit for bit.  With ONE library host thread per call (no threads started inside
+    engine creation and set_state: the units' first kernels follow their engines' creation most closely) this is the
+    configuration that exposed the null-stream fills of engine creation in round 5 (profiles/r05_concurrent_race.txt)."""
     import time
     import ccfindr_amd as C
     from ccfindr_amd import synth
+    from ccfindr_amd.engine import set_host_threads
     X = synth.drop_empty(synth.simulate_data(400, (100, 150, 250), seed=9, sparse=True))
     M = C.CountMatrix(X)
     kw = dict(ranks=range(2, 8), nrun=3, verbose=0, Tol=1e-6, seed=11, Itmax=1500, unif_stop=False)
-    t0 = time.perf_counter(); a = C.vb_factorize(M, **kw); ta = time.perf_counter() - t0
-    t0 = time.perf_counter(); b = C.vb_factorize(M, concurrent=4, **kw); tb = time.perf_counter() - t0
+    set_host_threads(host_threads)
+    try:
+        t0 = time.perf_counter(); a = C.vb_factorize(M, **kw); ta = time.perf_counter() - t0
+        t0 = time.perf_counter(); b = C.vb_factorize(M, concurrent=4, **kw); tb = time.perf_counter() - t0
+    finally:
+        set_host_threads(0)
     assert a.ranks == b.ranks and a.measure == b.measure and a.nsteps == b.nsteps
     for x, y in zip(a.basis + a.coeff, b.basis + b.coeff):
         assert np.array_equal(x, y)
