@@ -1,0 +1,27 @@
+"""Small matrices (the reference's shipped data set is 1030 x 450): a step is latency bound (~32 us, two or three dependent kernels),
+so the rank sweep's independent (run, rank) units are the parallelism there is.  vb_factorize(concurrent=K) keeps K units in flight
+on K streams from K host threads: aggregate iterations per second against K, fixed number of iterations per unit."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.getcwd())
+import ccfindr_amd as C
+from ccfindr_amd import synth
+
+X = synth.drop_empty(synth.simulate_data(1030, (150, 150, 150), seed=3, sparse=True))
+M = C.CountMatrix(X)
+ranks = list(range(2, 10))
+nrun = 4
+Itmax = 600
+kw = dict(ranks=ranks, nrun=nrun, verbose=0, Tol=0.0, seed=5, Itmax=Itmax, unif_stop=False, hyper_update_n0=10)
+units = len(ranks) * nrun
+C.vb_factorize(M, ranks=[2, 3], nrun=1, verbose=0, Tol=0.0, seed=1, Itmax=20)        # warm the device and the layouts
+print(f"{X.shape[0]} x {X.shape[1]}, nnz {X.nnz}: {units} units (ranks {ranks[0]}..{ranks[-1]} x {nrun} runs) of {Itmax} iterations each")
+base = None
+for K in (1, 2, 4, 8, 16):
+    t0 = time.perf_counter()
+    out = C.vb_factorize(M, concurrent=K, **kw) if K > 1 else C.vb_factorize(M, **kw)
+    dt = time.perf_counter() - t0
+    its = units * Itmax / dt
+    base = base or its
+    print(f"   concurrent={K:2d}: {dt:6.3f} s  {its:9.0f} iterations/s in all  ({its / base:4.2f} x)", flush=True)
+M.close()
