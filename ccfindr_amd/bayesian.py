@@ -17,6 +17,7 @@ count matrix itself and returns a plain result object holding the slots the refe
 from __future__ import annotations
 
 import math
+import os
 import threading
 import warnings
 from dataclasses import dataclass, field
@@ -27,6 +28,8 @@ from . import _native as N
 from .engine import EPS, CountMatrix, VBEngine, geometry_rank_for, rank_classes
 
 import ctypes
+
+BATCH_MAX_RANK = 16          # ranks the batch kernels are built for (csrc/engine.hip: kBatchMaxPaddedRank)
 
 
 # ---------------------------------------------------------------------------------------
@@ -243,22 +246,26 @@ def _bundle_rng(bundle, irun, rank):
     return np.random.default_rng(None if seed is None else [int(seed), int(irun), int(rank)])
 
 
-def _engine_key(bundle, rank):
-    # under `concurrent` > 1 each worker thread keeps its own engines: an engine serves one host thread at a time
+def _engine_key(bundle, rank, slot=None):
+    # under `concurrent` > 1 each worker thread keeps its own engines: an engine serves one host thread at a time;
+    # a batch of restarts (vb_run_rank_batch) keeps one engine per slot of the batch
+    if slot is not None:
+        return ("slot", slot, rank)
     return (threading.get_ident(), rank) if bundle.get("concurrent", 1) > 1 else rank
 
 
-def _make_engine(bundle, rank):
+def _make_engine(bundle, rank, slot=None):
     """The engine of one rank.  Building one means cutting the tiled layout of X for that rank on the host (seconds
     at C3), so the restarts of a rank (``nrun`` > 1) share it: ``bundle["engines"]`` keeps one per rank until
     ``_close_engines``."""
     cache = bundle.get("engines")
-    key = _engine_key(bundle, rank)
+    key = _engine_key(bundle, rank, slot)
     if cache is not None and key in cache:
         return cache[key]
     factory = bundle.get("engine_factory")
     eng = (factory(bundle["mat"], rank) if factory is not None else
-           VBEngine(bundle["mat"], rank, device=bundle.get("device", 0), geometry_rank=geometry_rank_for(rank, bundle.get("classes"))))
+           VBEngine(bundle["mat"], rank, device=bundle.get("device", 0), geometry_rank=geometry_rank_for(rank, bundle.get("classes")),
+                    grid=bundle.get("grid")))
     if cache is not None:
         cache[key] = eng
     return eng
@@ -341,15 +348,109 @@ def vb_run_rank(irun, rank, bundle):
     if verbose >= 2:
         print(f"Rank = {rank}: Nsteps ={it}, log(evidence) ={lk0}, hyper = ({hyper['aw']},{hyper['bw']},"
               f"{hyper['ah']},{hyper['bh']})")
+    return _unit_record(rank, bundle, wh, slots is not None, lk0, hyper, it)
+
+
+def _unit_record(rank, bundle, wh, in_place, lk0, hyper, it):
+    """The per-rank record vb_iterate stores (reference R/bayesian.R:368-369, 382-383) from a finished unit's state."""
     ew = wh["ew"]
     contains_unif = np.abs(ew.max(axis=0) - ew.min(axis=0)) < bundle["Tol"]      # :368-369
-    if slots is not None:                                                        # sqrt in place: the storage is the record
+    if in_place:                                                                 # sqrt in place: the storage is the record
         np.sqrt(wh["dw"], out=wh["dw"]); np.sqrt(wh["dh"], out=wh["dh"])
         sdw, sdh = wh["dw"], wh["dh"]
     else:
         sdw, sdh = np.sqrt(wh["dw"]), np.sqrt(wh["dh"])
     return {"rank": rank, "lk0": lk0, "ew": wh["ew"], "eh": wh["eh"], "sdw": sdw, "sdh": sdh,  # :382-383
             "hyper": hyper, "nsteps": it, "unif": [int(c) + 1 for c in np.nonzero(contains_unif)[0]]}
+
+
+def vb_run_rank_batch(iruns, rank, bundle):
+    """The restarts ``iruns`` of ONE rank (reference R/bayesian.R:260-261: ``lapply(seq_len(nrun), vb_iterate)``; here rank by
+    rank), stepped together by ``engine.run_batch``: on a small matrix one loop cannot fill the GPU and concurrent streams do
+    not overlap (profiles/r05_small_concurrent.txt), so the independent loops share their launches.  Every unit draws its
+    start from its own (run, rank) stream and follows its own control block: the records are vb_run_rank's, bit for bit."""
+    from .engine import run_batch
+    X = bundle["mat"]
+    nrow, ncol = X.shape
+    if rank > min(nrow, ncol):
+        raise ValueError("Rank exceeded min(nrow,ncol)")                         # :319-320
+    ga, gb = np.atleast_1d(bundle["gamma_a"]), np.atleast_1d(bundle["gamma_b"])
+    raw = bundle.get("raw")
+    engines, hypers = [], []
+    for slot, irun in enumerate(iruns):
+        hyper = {"aw": float(ga[0]), "ah": float(ga[-1]), "bw": float(gb[0]), "bh": float(gb[-1])}   # :321-326
+        rng = _bundle_rng(bundle, irun, rank)
+        eng = _make_engine(bundle, rank, slot)
+        on_device = bundle.get("device_init") and bundle["initializer"] == "random" and hasattr(eng, "random_state")
+        if on_device:
+            eng.random_state(hyper, int(rng.integers(1 << 63)))                  # :111-115 on the GPU
+        else:
+            wh0 = vb_init(nrow, ncol, raw if raw is not None else X, rank, hyper=hyper,
+                          initializer=bundle["initializer"], rng=rng, device=bundle.get("device", 0))
+            eng.set_state(wh0["lw"], wh0["lh"], wh0["eh"])
+        engines.append(eng); hypers.append(hyper)
+    outs = run_batch(engines, hypers, Itmax=bundle["Itmax"], Tol=bundle["Tol"], n0=bundle["hyper_update_n0"],
+                     dn=bundle["hyper_update_dn"], flags=bundle["hyper_update"], fudge=bundle["fudge"])
+    if any(o["reason"] == 3 for o in outs):
+        raise RuntimeError("Hyper-parameter update failed to converge")          # reference R/bayesian.R:43
+    recs = []
+    for irun, eng, out in zip(iruns, engines, outs):
+        slots = bundle["state_out"](irun, rank) if bundle.get("state_out") is not None else None
+        if slots is not None and getattr(eng, "supports_state_out", False):
+            wh = eng.get_state(("ew", "eh", "dw", "dh"), out=slots)
+        else:
+            wh = eng.get_state(("ew", "eh", "dw", "dh"))
+            if slots is not None:
+                for key in ("ew", "eh", "dw", "dh"):
+                    slots[key][...] = wh[key]
+                wh = slots
+        if bundle["verbose"] >= 2:
+            hy = out["hyper"]
+            print(f"Run {irun} rank = {rank}: Nsteps ={out['it']}, log(evidence) ={out['lk0']}, hyper = ({hy['aw']},{hy['bw']},"
+                  f"{hy['ah']},{hy['bh']})")
+        recs.append(_unit_record(rank, bundle, wh, slots is not None, out["lk0"], out["hyper"], out["it"]))
+    return recs
+
+
+def batch_eligible(bundle, batch):
+    """How many restarts of a rank vb_factorize steps together: ``batch`` as given (1: never), or -- ``None`` -- up to 16 where
+    it pays and is possible: several runs, a matrix small enough that a step is latency bound (up to 4e6 stored entries),
+    ranks within the batch kernels' range, the device-driven loop, the library's own engines."""
+    nrun = bundle["nrun"]
+    if batch is not None and int(batch) <= 1:
+        return 1
+    ok = (nrun > 1 and bundle.get("engine_factory") is None and bundle.get("device_loop", True) and bundle["verbose"] < 3 and
+          bundle.get("concurrent", 1) == 1 and not getattr(bundle["mat"], "is_shell", False) and
+          max(bundle["ranks"], default=0) <= BATCH_MAX_RANK and os.environ.get("VBNMF_NO_UPDATE_PAIR", "0") != "1" and
+          os.environ.get("VBNMF_NO_CONTROL_FOLD", "0") != "1")
+    if not ok:
+        if batch is not None:
+            raise ValueError("batch > 1 needs nrun > 1, ranks <= %d, the device-driven loop and the library's own engines" % BATCH_MAX_RANK)
+        return 1
+    if batch is None:
+        return min(nrun, 16) if bundle["mat"].nnz <= 4_000_000 else 1
+    return min(int(batch), nrun, 64)
+
+
+def vb_iterate_batched(bundle, batch):
+    """All runs, rank by rank, the runs still scanning stepped ``batch`` at a time (vb_run_rank_batch); a run's scan ends at a
+    rank with a constant basis column under ``unif_stop`` exactly as in vb_iterate (reference R/bayesian.R:373-377)."""
+    ranks = [int(r) for r in bundle["ranks"]]
+    alive = list(range(1, bundle["nrun"] + 1))
+    records = {irun: {} for irun in alive}
+    for rank in ranks:
+        if not alive:
+            break
+        for c0 in range(0, len(alive), batch):
+            chunk = alive[c0:c0 + batch]
+            for irun, rec in zip(chunk, vb_run_rank_batch(chunk, rank, bundle)):
+                records[irun][rank] = rec
+        if bundle["unif_stop"]:
+            alive = [irun for irun in alive if not records[irun][rank]["unif"]]
+        cache = bundle.get("engines")                                            # this rank's engines are done with
+        for key in [k for k in (cache or {}) if isinstance(k, tuple) and k[0] == "slot" and k[2] == rank]:
+            cache.pop(key).close()
+    return [assemble_run(records[irun], ranks, bundle["unif_stop"]) for irun in range(1, bundle["nrun"] + 1)]
 
 
 def assemble_run(records, ranks, unif_stop):
@@ -456,7 +557,7 @@ def vb_factorize(mat, ranks=2, nrun=1, verbose=2, progress_bar=True, initializer
                  hyper_update=(True, True, True, True), gamma_a=1, gamma_b=1, Tol=1e-5,
                  hyper_update_n0=10, hyper_update_dn=1, connectivity=False, fudge=None, ncores=1,
                  useC=True, unif_stop=True, seed=None, device=0, engine_factory=None, device_loop=True, concurrent=1,
-                 device_init=False, geometry_classes=1):
+                 device_init=False, geometry_classes=1, batch=None, grid=None):
     """Bayesian NMF of a count matrix on the MI355X engine; reference R/bayesian.R:229-301.
 
     ``mat`` is the genes x cells count matrix (dense, scipy sparse, or ``CountMatrix``).
@@ -488,6 +589,7 @@ def vb_factorize(mat, ranks=2, nrun=1, verbose=2, progress_bar=True, initializer
     bundle["device_loop"] = bool(device_loop)      # False: step from the host (the loop below, literally)
     bundle["device_init"] = bool(device_init)
     bundle["concurrent"] = max(1, int(concurrent))
+    bundle["grid"] = grid                               # (sweep workgroups, update blocks) of every engine; None: one per CU
     bundle["engines"] = {} if (nrun > 1 or bundle["concurrent"] > 1) else None   # restarts of a rank reuse its engine
     plan_geometry(bundle, geometry_classes)
     try:
@@ -510,6 +612,11 @@ def vb_factorize(mat, ranks=2, nrun=1, verbose=2, progress_bar=True, initializer
             records = dict(zip(units, recs))
             vb = [assemble_run({r: records[(irun, int(r))] for r in bundle["ranks"]}, [int(r) for r in bundle["ranks"]], unif_stop)
                   for irun in range(1, nrun + 1)]
+        elif batch_eligible(bundle, batch) > 1:
+            from .engine import batch_grid
+            nb = batch_eligible(bundle, batch)
+            bundle["grid"] = batch_grid(nb) if grid is None else grid          # B engines x 256 / B workgroups: one launch fills the chip
+            vb = vb_iterate_batched(bundle, nb)                                  # :260-261, the runs of a rank in one launch
         else:
             vb = [vb_iterate(irun, bundle) for irun in range(1, nrun + 1)]       # :260-261
     finally:

@@ -187,6 +187,9 @@ int dev_upload(T **p, const std::vector<T, A> &v)
 }  // namespace
 
 namespace vbnmf {
+// vbnmf_set_engine_grid: the grids of the engines THIS host thread creates next (0: the defaults)
+static thread_local int tl_grid_nwg = 0, tl_grid_ub = 0;
+
 int sweep_workgroups(int device, bool partitioned, int &n_wg)
 {
     hipDeviceProp_t prop;
@@ -1031,11 +1034,13 @@ int vbnmf_engine_create_geom(const vbnmf_matrix *X, int64_t cb, int64_t ce, int6
         // per wave instruction) that 256 CUs' texture units share and 2 do not.  VBNMF_UPDATE_BLOCKS overrides (experiments).
         int ub = kUpdateBlocks;
         if (const char *sv = getenv("VBNMF_UPDATE_BLOCKS")) { int v = atoi(sv); if (v >= 1 && v <= kUpdateBlocks) ub = v; }
+        if (tl_grid_ub > 0) ub = std::min(ub, tl_grid_ub);          // (engines meant for a batch: vbnmf_set_engine_grid)
         e->ub = ub;
     }
     e->wide = !X->M.counts_int;
     e->partitioned = (ce - cb) != m_global;
     if (int rc = sweep_workgroups(device, e->partitioned, e->n_wg)) { delete e; return rc; }
+    if (!e->partitioned && tl_grid_nwg > 0) e->n_wg = std::min(e->n_wg, tl_grid_nwg);
     int rc = VBNMF_OK;
     auto bail = [&](int code) { vbnmf_engine_destroy(e); return code; };
     {
@@ -1922,6 +1927,267 @@ int vbnmf_engine_run(vbnmf_engine *e, double *hyper, double fudge, int32_t max_i
         G.comm = e->comm;
     }
     return run_group(G, hyper, fudge, max_it, tol, n0, dn, flags, it_out, lk0_out, lkh_out, reason_out, history, history_rows);
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------- a batch of engines stepped by one launch (kernels.h: k_update2_batch)
+namespace {
+
+#ifdef VBNMF_DEV_FEW_RANKS
+#define VBNMF_FOR_EACH_R_BATCH(X) X(4) X(6) X(8) X(10)
+#else
+#define VBNMF_FOR_EACH_R_BATCH(X) X(2) X(4) X(6) X(8) X(10) X(12) X(14) X(16)
+#endif
+constexpr int kBatchMaxPaddedRank = 16;      // the small-matrix regime the batch is for (instantiations cost build time)
+constexpr int kBatchMax = 64;
+
+template <int R, bool WIDE>
+int launch_sweep_batch_t(vbnmf_engine *e, const SweepSide *jobs, int B)
+{
+    constexpr int NT = sweep_threads(R);
+    static std::atomic<bool> attr_set[16];
+    const void *fn = (const void *)k_sweep_batch<R, WIDE, NT, 1>;
+    if (e->device >= 16 || !attr_set[e->device].load(std::memory_order_acquire)) {
+        if (int rc = prepare_sweep_kernel(fn)) return rc;
+        if (e->device < 16) attr_set[e->device].store(true, std::memory_order_release);
+    }
+    hipLaunchKernelGGL((k_sweep_batch<R, WIDE, NT, 1>), dim3((unsigned)e->n_wg, (unsigned)B), dim3(NT), e->lds_bytes, e->stream, jobs);
+    HIPCHECK(hipGetLastError());
+    return VBNMF_OK;
+}
+
+int launch_sweep_batch(vbnmf_engine *e, const SweepSide *jobs, int B)
+{
+    switch (e->R) {
+#define X(RR) case RR: return e->wide ? launch_sweep_batch_t<RR, true>(e, jobs, B) : launch_sweep_batch_t<RR, false>(e, jobs, B);
+        VBNMF_FOR_EACH_R_BATCH(X)
+#undef X
+        default: return fail(VBNMF_ERR_BAD_ARG, "a batch serves padded ranks up to %d (this engine: %d)", kBatchMaxPaddedRank, e->R);
+    }
+}
+
+int launch_update2_batch(vbnmf_engine *e, const Upd2Job *jobs, int B)
+{
+    switch (e->R) {
+#define X(RR) case RR: hipLaunchKernelGGL((k_update2_batch<RR>), dim3((unsigned)e->ub, (unsigned)B), dim3(kUpdateThreads), 0, e->stream, jobs); break;
+        VBNMF_FOR_EACH_R_BATCH(X)
+#undef X
+        default: return fail(VBNMF_ERR_BAD_ARG, "a batch serves padded ranks up to %d (this engine: %d)", kBatchMaxPaddedRank, e->R);
+    }
+    HIPCHECK(hipGetLastError());
+    return VBNMF_OK;
+}
+
+// the fold of step t (1-based) of engine e's run, as queue_vb_step builds it
+ControlFold batch_fold(const vbnmf_engine *e, int t, bool hist)
+{
+    ControlFold f{};
+    f.prev = e->ctl2 + ((t - 1) & 1); f.next = e->ctl2 + (t & 1);
+    f.epart = e->epart; f.nepart = 2 * (int64_t)e->n_wg;
+    f.lgx = e->lgx; f.n = (double)e->n; f.m_global = (double)e->m_global;
+    f.history = hist ? e->h_hist_dev : nullptr; f.out_host = e->h_out_dev;
+    f.do_control = t > 1 ? 1 : 0;
+    return f;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Grids of the engines the CALLING host thread creates from now on: `n_wg` persistent workgroups of the sweep (the layouts
+// are cut for that many) and `update_blocks` blocks of the update; 0 = the default (one per CU).  For the engines of a batch:
+// B engines step in one launch of B x grid workgroups, so a batch of 8 wants grids of 32 -- a single small engine is
+// faster on 256 (every block's share of a 15 us kernel is its prologue), eight of them are not (eight such blocks per CU).
+// The grid fixes the order of the block-wise sums: engines of different grids agree to rounding, not bit for bit.
+int vbnmf_set_engine_grid(int32_t n_wg, int32_t update_blocks)
+{
+    if (n_wg < 0 || update_blocks < 0 || update_blocks > kUpdateBlocks) return fail(VBNMF_ERR_BAD_ARG, "grid sizes must lie in [0, %d]", kUpdateBlocks);
+    tl_grid_nwg = n_wg; tl_grid_ub = update_blocks;
+    return VBNMF_OK;
+}
+
+// The device-driven loops of `count` engines of ONE rank on ONE matrix (the restarts of a rank: same layouts, grids and update
+// table; each engine its own state), stepped TOGETHER: two launches per step for the whole batch, every engine's blocks
+// following its own control block (its own hyper-parameters, evidence, stop).  Results per engine are those of
+// vbnmf_engine_run on it alone, bit for bit.  hyper: [count][4] in / out; it / lk0 / lkh / reason: [count]; history (or
+// null): [count][history_rows][9].  Engines must be unpartitioned, of the one-launch update form, of padded rank <= 16.
+int vbnmf_batch_run(vbnmf_engine **engs, int32_t count, double *hyper, double fudge, int32_t max_it, double tol, int32_t n0,
+                    int32_t dn, const int32_t *flags, int32_t *it_out, double *lk0_out, double *lkh_out, int32_t *reason_out,
+                    double *history, int64_t history_rows)
+{
+    if (!engs || !hyper || !flags) return fail(VBNMF_ERR_BAD_ARG, "NULL argument");
+    if (count < 1 || count > kBatchMax) return fail(VBNMF_ERR_BAD_ARG, "a batch holds 1 to %d engines", kBatchMax);
+    if (max_it < 1 || dn < 1) return fail(VBNMF_ERR_BAD_ARG, "max_it and dn must be >= 1");
+    if (history && history_rows < max_it) return fail(VBNMF_ERR_BAD_ARG, "history needs max_it rows of 9 doubles per engine");
+    vbnmf_engine *e0 = engs[0];
+    if (!e0) return fail(VBNMF_ERR_BAD_ARG, "engine handle is NULL");
+    const int B = count;
+    for (int b = 0; b < B; b++) {
+        vbnmf_engine *e = engs[b];
+        if (!e) return fail(VBNMF_ERR_BAD_ARG, "engine handle is NULL");
+        for (int q = 0; q < b; q++) if (engs[q] == e) return fail(VBNMF_ERR_BAD_ARG, "the same engine twice in a batch");
+        if (int rc = use_device(e)) return rc;
+        if (e->partitioned || e->comm || !e->pair || !e->fold || e->R > kBatchMaxPaddedRank)
+            return fail(VBNMF_ERR_STATE, "a batch takes unpartitioned engines of the one-launch update form and padded rank <= %d", kBatchMaxPaddedRank);
+        if (e->device != e0->device || e->n != e0->n || e->m != e0->m || e->r != e0->r || e->R != e0->R || e->n_wg != e0->n_wg || e->ub != e0->ub ||
+            e->NT != e0->NT || e->wide != e0->wide || e->lds_bytes != e0->lds_bytes || e->upd_stride4 != e0->upd_stride4 || e->upd_V != e0->upd_V ||
+            e->upd_ids_off != e0->upd_ids_off || e->A.n_slices != e0->A.n_slices || e->B.n_slices != e0->B.n_slices)
+            return fail(VBNMF_ERR_STATE, "the engines of a batch must be of one rank on one matrix (same layouts, grids and update table)");
+        if (!e->has_state || !e->stats_ready) return fail(VBNMF_ERR_STATE, "batch run before set_state");
+        if (e->step_pending) return fail(VBNMF_ERR_STATE, "batch run between step_local and step_finish");
+        if (history) { if (int rc = ensure_history(e, (size_t)max_it * 9)) return rc; }
+    }
+    hipStream_t S = e0->stream;
+    for (int b = 1; b < B; b++) HIPCHECK(hipStreamSynchronize(engs[b]->stream));      // (idle already: set_state ends with a synchronise)
+
+    // ---- the jobs: the update's of step 1 (nothing to evaluate yet), of the odd and of the even steps; the sweep's by parity
+    const bool hist = history != nullptr;
+    std::vector<Upd2Job> ju((size_t)3 * B);
+    std::vector<SweepSide> js((size_t)2 * 2 * B);
+    std::vector<hipStream_t> own(B);
+    std::vector<bool> timing(B);
+    for (int b = 0; b < B; b++) {
+        vbnmf_engine *e = engs[b];
+        own[b] = e->stream; timing[b] = e->timing;
+        e->timing = false; e->ev_recorded = false; e->ev2_recorded = false;
+        double *Wt[2] = {e->bpW, e->bpW_alt}, *Ht[2] = {e->bpH, e->bpH_alt};          // [0]: the latest tables as the run starts
+        for (int v = 0; v < 3; v++) {
+            const int t = v == 0 ? 1 : (v == 1 ? 3 : 2);
+            Upd2Job &J = ju[(size_t)v * B + b];
+            J.W.part = e->A.part; J.W.nmaj = e->n; J.W.l = e->lw; J.W.ll = e->llw; J.W.e = e->ew; J.W.d = e->dw;
+            J.H.part = e->B.part; J.H.nmaj = e->m; J.H.l = e->lh; J.H.ll = e->llh; J.H.e = e->eh; J.H.d = e->dh;
+            J.W.bp_prev = Wt[(t - 1) & 1]; J.W.bp = Wt[t & 1];
+            J.H.bp_prev = Ht[(t - 1) & 1]; J.H.bp = Ht[t & 1];
+            J.T = UpdTable{e->upd_tab, e->upd_stride4, e->upd_V, e->upd_ids_off};
+            J.r = e->r; J.nb = e->ub; J.ncs = e->n_wg; J.csum = e->csum; J.fudge = fudge;
+            J.fold = batch_fold(e, t, hist);
+        }
+        e->run_active = true;
+        for (int par = 0; par < 2; par++) {                       // the sweep of step t reads the stop flag that step's update left
+            e->stop_ptr = &(e->ctl2 + par)->stop;
+            js[((size_t)par * B + b) * 2] = sweep_side_args(e, e->A, true, e->epart);
+            js[((size_t)par * B + b) * 2 + 1] = sweep_side_args(e, e->B, false, e->epart + e->n_wg);
+        }
+        e->stop_ptr = nullptr;
+    }
+    Upd2Job *d_ju = nullptr;
+    SweepSide *d_js = nullptr;
+    auto restore = [&](int rc) {
+        for (int b = 0; b < B; b++) {
+            vbnmf_engine *e = engs[b];
+            e->stream = own[b];
+            e->run_active = false; e->timing = timing[b]; e->stop_ptr = nullptr;
+            e->seq = 0.0; e->h_out[7] = 0.0;
+        }
+        dev_free(d_ju); dev_free(d_js);
+        return rc;
+    };
+    if (int rc = dev_upload(&d_ju, ju)) return restore(rc);
+    if (int rc = dev_upload(&d_js, js)) return restore(rc);
+    for (int b = 0; b < B; b++) {
+        vbnmf_engine *e = engs[b];
+        LoopCtl c{};
+        for (int q = 0; q < 4; q++) { c.hyper[q] = hyper[(size_t)b * 4 + q]; c.flags[q] = flags[q] ? 1 : 0; }
+        c.lk0 = 0.0;
+        c.tol = tol; c.max_it = max_it; c.n0 = n0; c.dn = dn;
+        hipLaunchKernelGGL(k_ctl_init, dim3(1), dim3(1), 0, S, e->ctl2, c);
+        e->fold_step = 0;
+        volatile double *ho = e->h_out;
+        ho[5] = 0.0; ho[6] = 0.0; ho[7] = 0.0;
+        e->stream = S;                                           // every launch of the run goes on the first engine's stream
+    }
+    {
+        hipError_t he = hipGetLastError();
+        if (he != hipSuccess) { (void)hipStreamSynchronize(S); return restore(fail(VBNMF_ERR_HIP, "loading the loop control blocks failed: %s", hipGetErrorString(he))); }
+    }
+
+    // ---- the loop: steps queued in batches of eight, two batches ahead of the device (drive_loop's rule, over all engines)
+    int queued = 0;
+    auto queue_step = [&]() -> int {
+        const int t = queued + 1;
+        const int v = t == 1 ? 0 : ((t & 1) ? 1 : 2);
+        if (int rc = launch_update2_batch(e0, d_ju + (size_t)v * B, B)) return rc;
+        if (int rc = launch_sweep_batch(e0, d_js + (size_t)(t & 1) * B * 2, B)) return rc;
+        for (int b = 0; b < B; b++) {
+            vbnmf_engine *e = engs[b];
+            std::swap(e->bpW, e->bpW_alt); std::swap(e->bpH, e->bpH_alt);      // (e->bpW / e->bpH name the latest tables, as launch_update2 keeps them)
+            e->fold_step = t;
+        }
+        if (t == max_it) {                                       // behind the last step: every engine's control step alone
+            for (int b = 0; b < B; b++) {
+                vbnmf_engine *e = engs[b];
+                ControlFold g = batch_fold(e, t + 1, hist);
+                g.bpW_prev = e->bpW;
+                g.do_control = 1; g.control_only = 1;
+                if (int rc = launch_update(e, true, 0, 0, fudge, nullptr, &g)) return rc;
+            }
+        }
+        queued++;
+        return VBNMF_OK;
+    };
+    auto queue_batch = [&]() -> int {
+        for (int q = 0; q < 8 && queued < max_it; q++) if (int rc = queue_step()) return rc;
+        return VBNMF_OK;
+    };
+    auto fail_out = [&](int rc) {
+        std::string msg = last_error_cstr();
+        if (e0->poisoned) { for (int b = 0; b < B; b++) { engs[b]->poisoned = true; engs[b]->stream = own[b]; } return fail(rc, "%s", msg.c_str()); }
+        (void)hipStreamSynchronize(S);
+        restore(rc);
+        return fail(rc, "%s", msg.c_str());
+    };
+    if (int rc = queue_batch()) return fail_out(rc);
+    if (int rc = queue_batch()) return fail_out(rc);
+    const double limit = wait_timeout_s();
+    for (int bt = 0;; bt++) {
+        const int target = (int)std::min<int64_t>((int64_t)(bt + 1) * 8, max_it);
+        const auto t0 = std::chrono::steady_clock::now();
+        bool all_stopped = false;
+        for (long spins = 1;; spins++) {
+            bool reached = true;
+            all_stopped = true;
+            for (int b = 0; b < B; b++) {
+                volatile double *ho = engs[b]->h_out;
+                const bool stopped = ho[6] != 0.0;
+                all_stopped = all_stopped && stopped;
+                reached = reached && (stopped || (int)ho[7] >= target);
+            }
+            if (reached) break;
+            if ((spins & 0xFFFF) == 0) {
+                const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                if (waited > limit) {
+                    e0->poisoned = true;
+                    return fail_out(fail(VBNMF_ERR_HIP, "timed out after %.1f s (VBNMF_WAIT_TIMEOUT_S) waiting for step %d of a batch's device-driven loop (%d queued)", waited, target, queued));
+                }
+                hipError_t q = hipStreamQuery(S);
+                if (q != hipSuccess && q != hipErrorNotReady) return fail_out(fail(VBNMF_ERR_HIP, "the batch's loop failed on the device: %s", hipGetErrorString(q)));
+                if (q == hipSuccess) {                            // idle: everything queued has run; look once more, then it is lost
+                    bool ok = true;
+                    const int expect = queued - (queued < max_it ? 1 : 0);
+                    for (int b = 0; b < B; b++) { volatile double *ho = engs[b]->h_out; ok = ok && (ho[6] != 0.0 || (int)ho[7] >= std::min(target, expect)); }
+                    if (!ok) return fail_out(fail(VBNMF_ERR_HIP, "the device went idle before the queued steps of the batch finished"));
+                }
+            }
+        }
+        if (all_stopped || target >= max_it) break;
+        if (int rc = queue_batch()) return fail_out(rc);
+    }
+    {
+        hipError_t he = hipStreamSynchronize(S);
+        if (he != hipSuccess) return restore(fail(VBNMF_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(he)));
+    }
+    for (int b = 0; b < B; b++) {
+        const double *ho = engs[b]->h_out;
+        const int it = (int)ho[5];
+        for (int q = 0; q < 4; q++) hyper[(size_t)b * 4 + q] = ho[8 + q];
+        if (it_out) it_out[b] = it;
+        if (lk0_out) lk0_out[b] = ho[12];
+        if (lkh_out) lkh_out[b] = ho[0];
+        if (reason_out) reason_out[b] = (int)ho[6];
+        if (history && it > 0) std::memcpy(history + (size_t)b * (size_t)history_rows * 9, engs[b]->h_hist, (size_t)it * 9 * sizeof(double));
+    }
+    return restore(VBNMF_OK);
 }
 
 // ---------------------------------------------------------------- communicators (comm.h)

@@ -725,6 +725,17 @@ __global__ __launch_bounds__(NT) void k_sweep(const SweepSide A, const SweepSide
 #endif
 }
 
+// The sweeps of a batch of engines (k_update2_batch above): jobs[2 b] = gene side, jobs[2 b + 1] = cell side of engine b.
+template <int R, bool WIDE, int NT, int SP = 1>
+__global__ __launch_bounds__(NT) void k_sweep_batch(const SweepSide *__restrict__ jobs)
+{
+    extern __shared__ double2 ldsG[];
+    const SweepSide A = jobs[2 * blockIdx.y], B = jobs[2 * blockIdx.y + 1];
+    if (A.stop && *A.stop) return;
+    sweep_side<R, WIDE, true, NT, 1, SP>(A, ldsG);
+    sweep_side<R, WIDE, false, NT, 1, SP>(B, ldsG, &A);
+}
+
 // One side alone (ML-NMF: its H and W updates are sequential, reference R/factorize.R:8-24, so each needs its
 // own pass over X; the cell-side pass also yields the likelihood's sum x log(wh)).
 // VB = true: one side of the VB sweep launched alone, with the VB evidence partial (EV = 1): cell-partitioned engines
@@ -1186,9 +1197,9 @@ __device__ __forceinline__ int posterior_visits(const UpdSide &S, int64_t m0, co
 }
 
 template <int R>
-__global__ __launch_bounds__(kUpdateThreads) void k_update2(
-    const UpdSide W, const UpdSide H, const UpdTable T, int r, int nb, const double *__restrict__ csum, int ncs,
-    double aw, double bw, double ah, double bh, double fudge, const LoopCtl *__restrict__ ctl, const ControlFold fold)
+__device__ __forceinline__ void update2_body(
+    const UpdSide &W, const UpdSide &H, const UpdTable &T, int r, int nb, const double *__restrict__ csum, int ncs,
+    double aw, double bw, double ah, double bh, double fudge, const LoopCtl *__restrict__ ctl, const ControlFold &fold)
 {
     constexpr int RB = kUpdateThreads / R;
     __shared__ double s_other[R + 2], s_cs[R + 2], sW[R + 2], s_hy[4];
@@ -1356,6 +1367,38 @@ __global__ __launch_bounds__(kUpdateThreads) void k_update2(
         oH[R] = st; oH[R + 1] = sl;
     }
     UPD2_STAMP(7);
+}
+
+template <int R>
+__global__ __launch_bounds__(kUpdateThreads) void k_update2(
+    const UpdSide W, const UpdSide H, const UpdTable T, int r, int nb, const double *__restrict__ csum, int ncs,
+    double aw, double bw, double ah, double bh, double fudge, const LoopCtl *__restrict__ ctl, const ControlFold fold)
+{
+    update2_body<R>(W, H, T, r, nb, csum, ncs, aw, bw, ah, bh, fudge, ctl, fold);
+}
+
+// ------------------------------------------------------------------------------------
+// A BATCH of engines stepped by one launch (vbnmf_batch_run): the restarts of one rank on one matrix -- same layouts, same
+// table, same grids, each with its own state, partials and control block -- take one row of the grid each (blockIdx.y).  On the
+// matrices the reference ships (1030 x 450) a step is two dependent launches of ~15 us for microseconds of work on a dozen
+// workgroups, and the device runs the launches of different streams (let alone processes) mostly one after the other
+// (profiles/r05_small_concurrent.txt): the independent units of a rank sweep share a launch instead.  The bodies are the
+// single engine's, so every unit's results are its stand-alone results bit for bit.
+// ------------------------------------------------------------------------------------
+struct Upd2Job {
+    UpdSide W, H;
+    UpdTable T;
+    int32_t r, nb, ncs;
+    const double *csum;
+    double fudge;
+    ControlFold fold;              // (the batch always runs the device-driven loop with the control step folded in)
+};
+
+template <int R>
+__global__ __launch_bounds__(kUpdateThreads) void k_update2_batch(const Upd2Job *__restrict__ jobs)
+{
+    const Upd2Job J = jobs[blockIdx.y];
+    update2_body<R>(J.W, J.H, J.T, J.r, J.nb, J.csum, J.ncs, 0.0, 0.0, 0.0, 0.0, J.fudge, nullptr, J.fold);
 }
 
 // State load (set_state): ll = l*log(l) and the block partials of e's column sums, same

@@ -255,17 +255,25 @@ class _CudaBuffer:
 class VBEngine:
     """Device-resident state of one factorisation (one rank, one column block of X)."""
 
-    def __init__(self, X: CountMatrix, rank: int, device: int = 0, cols=None, m_global=None, geometry_rank: int = 0):
+    def __init__(self, X: CountMatrix, rank: int, device: int = 0, cols=None, m_global=None, geometry_rank: int = 0, grid=None):
         """``geometry_rank`` (>= rank): the rank whose LDS row size the tiled layouts are cut for -- the ranks of a sweep
-        share one pair of layouts (``rank_classes``); 0: the matrix's plan (``CountMatrix.plan_ranks``) or the rank's own."""
+        share one pair of layouts (``rank_classes``); 0: the matrix's plan (``CountMatrix.plan_ranks``) or the rank's own.
+        ``grid`` = (sweep workgroups, update blocks): an engine meant for a batch of B (``run_batch``) wants 256 / B of each
+        (``vbnmf_set_engine_grid``); None: one per CU."""
         L = N.load()
         self._lib = L
         self._h = ctypes.c_void_p()
         self.X = X
         cb, ce = (0, X.shape[1]) if cols is None else cols
         mg = X.shape[1] if m_global is None else m_global
-        N.check(L.vbnmf_engine_create_geom(X._h, int(cb), int(ce), int(mg), int(rank), int(geometry_rank), int(device),
-                                           ctypes.byref(self._h)))
+        if grid is not None:
+            N.check(L.vbnmf_set_engine_grid(int(grid[0]), int(grid[1])))
+        try:
+            N.check(L.vbnmf_engine_create_geom(X._h, int(cb), int(ce), int(mg), int(rank), int(geometry_rank), int(device),
+                                               ctypes.byref(self._h)))
+        finally:
+            if grid is not None:
+                L.vbnmf_set_engine_grid(0, 0)
         n, m, r = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int32()
         N.check(L.vbnmf_engine_dims(self._h, ctypes.byref(n), ctypes.byref(m), ctypes.byref(r)))
         self.n, self.m, self.rank = n.value, m.value, r.value
@@ -479,6 +487,36 @@ class VBEngine:
             self.close()
         except Exception:
             pass
+
+
+def batch_grid(B):
+    """Grid of the engines of a batch of B: 256 / B workgroups and blocks each (a multiple of 8 -- one per XCD --, at least 8)."""
+    g = max(8, (256 // max(1, int(B))) // 8 * 8)
+    return (g, g)
+
+
+def run_batch(engines, hypers, Itmax=10000, Tol=1e-5, n0=10, dn=1, flags=(True,) * 4, fudge=EPS, history=False):
+    """The device-driven loops of several engines of ONE rank on ONE ``CountMatrix`` -- the restarts of a rank, reference
+    R/bayesian.R:260-261 -- stepped together (``vbnmf_batch_run``: two launches per step for the whole batch).  Every
+    engine has had its state set; ``hypers`` holds one mapping per engine.  Returns one ``VBEngine.run`` result per engine,
+    bit for bit what ``run`` gives on that engine alone; ``reason`` 3 (hyper-parameter Newton failed) is returned, not
+    raised: the other engines' results are valid."""
+    B = len(engines)
+    if B < 1 or len(hypers) != B:
+        raise ValueError("one hyper-parameter mapping per engine")
+    lib = engines[0]._lib
+    hs = (ctypes.c_void_p * B)(*(e._h for e in engines))
+    hy = np.array([[float(h[k]) for k in ("aw", "bw", "ah", "bh")] for h in hypers], dtype=np.float64)
+    fl = (ctypes.c_int32 * 4)(*(1 if f else 0 for f in flags))
+    it = np.zeros(B, dtype=np.int32); reason = np.zeros(B, dtype=np.int32)
+    lk0 = np.zeros(B); lkh = np.zeros(B)
+    hist = np.zeros((B, int(Itmax), 9)) if history else None
+    N.check(lib.vbnmf_batch_run(hs, B, N.dptr(hy), float(fudge), int(Itmax), float(Tol), int(n0), int(dn), fl,
+                                it.ctypes.data_as(N.c_int32_p), N.dptr(lk0), N.dptr(lkh), reason.ctypes.data_as(N.c_int32_p),
+                                N.dptr(hist), int(Itmax) if history else 0))
+    return [{"it": int(it[b]), "lk0": float(lk0[b]), "lkh": float(lkh[b]), "reason": int(reason[b]),
+             "hyper": dict(zip(("aw", "bw", "ah", "bh"), (float(v) for v in hy[b]))),
+             "history": hist[b, :it[b]].copy() if history else None} for b in range(B)]
 
 
 def _run_outputs(Itmax, history):

@@ -234,6 +234,26 @@ int vbnmf_engine_run(vbnmf_engine *e, double *hyper, double fudge, int32_t max_i
                      int32_t dn, const int32_t *flags, int32_t *it, double *lk0, double *lkh, int32_t *reason,
                      double *history, int64_t history_rows);
 
+/* The restarts of one rank, stepped together.  Reference: vb_factorize runs `nrun` independent factorisations of every
+ * rank, `lapply(seq_len(nrun), FUN = vb_iterate, bundle)` (R/bayesian.R:260-261; over Rmpi slaves at :262-263), each the loop of
+ * R/bayesian.R:337-352 from its own random start.  On the small matrices ccfindR ships (inst/extdata: 1030 x 450) one such
+ * loop cannot fill the GPU -- a step is two dependent launches of ~15 us for microseconds of work on a dozen workgroups -- and
+ * concurrent streams or processes do not overlap them (profiles/r05_small_concurrent.txt), so the independent loops share
+ * their launches instead: `count` engines of ONE rank on ONE matrix handle (same layouts, grids, update table; each engine
+ * its own state, set beforehand), every step two launches for the whole batch, every engine following its own control block
+ * (hyper-parameters, evidence, stop -- an engine that has stopped idles through the others' remaining steps).  Per engine the
+ * results are those of vbnmf_engine_run on it alone, bit for bit.  hyper: [count][4] in / out; it_out, lk0_out, lkh_out,
+ * reason_out: [count] (any may be NULL); history (or NULL): [count][history_rows][9], history_rows >= max_it.
+ * Engines: unpartitioned, no communicator, rank <= 16, count <= 64; the launches go on the first engine's stream. */
+/* Grids of the engines the CALLING host thread creates from now on (0, 0: back to the defaults, one workgroup / block per
+ * CU): engines meant for a batch of B want 256 / B of each -- B engines step in one launch of B x grid workgroups.  The
+ * grid is part of the order of the block-wise sums: engines of different grids agree to rounding, not bit for bit.  (No
+ * reference counterpart: launch geometry.) */
+int vbnmf_set_engine_grid(int32_t n_wg, int32_t update_blocks);
+int vbnmf_batch_run(vbnmf_engine **engines, int32_t count, double *hyper, double fudge, int32_t max_it, double tol,
+                    int32_t n0, int32_t dn, const int32_t *flags, int32_t *it_out, double *lk0_out, double *lkh_out,
+                    int32_t *reason_out, double *history, int64_t history_rows);
+
 /* ---------------------------------------------------------------------------------
  * Communicators for cell-partitioned runs.  The reference has no counterpart inside
  * an iteration: its only inter-process mechanism is Rmpi::mpi.applyLB over restarts (R/bayesian.R:262-263),

@@ -19,9 +19,17 @@ print(f"{X.shape[0]} x {X.shape[1]}, nnz {X.nnz}: {units} units (ranks {ranks[0]
 base = None
 for K in (1, 2, 4, 8, 16):
     t0 = time.perf_counter()
-    out = C.vb_factorize(M, concurrent=K, **kw) if K > 1 else C.vb_factorize(M, **kw)
+    out = C.vb_factorize(M, concurrent=K, batch=1, **kw) if K > 1 else C.vb_factorize(M, batch=1, **kw)
     dt = time.perf_counter() - t0
     its = units * Itmax / dt
     base = base or its
     print(f"   concurrent={K:2d}: {dt:6.3f} s  {its:9.0f} iterations/s in all  ({its / base:4.2f} x)", flush=True)
+# the restarts of a rank stepped by ONE launch (vbnmf_batch_run): nrun restarts per rank, batches of B
+for nrun_b, B in ((4, 2), (4, 4), (8, 8), (16, 16), (32, 32)):
+    kwb = dict(kw, nrun=nrun_b)
+    t0 = time.perf_counter()
+    out = C.vb_factorize(M, batch=B, **kwb)
+    dt = time.perf_counter() - t0
+    its = len(ranks) * nrun_b * Itmax / dt
+    print(f"   batch={B:2d} ({nrun_b:2d} runs per rank): {dt:6.3f} s  {its:9.0f} iterations/s in all  ({its / base:4.2f} x)", flush=True)
 M.close()
