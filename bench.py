@@ -38,7 +38,9 @@ vb_factorize_sharded, reference defaults: wall seconds of the call as the librar
 process --, per-rank iterations, and from a second call with ONE unit at a time the stepping / setup split per process;
 that second call finds the sweep's layouts already cut); at N > 1
 also `cells_partitioned` = config C5 (one factorisation, cells partitioned N-way, the library's all-reduce inside the
-device-driven loop) with its per-GPU roofline and `allreduce_ms` (events around the collective).
+device-driven loop) with its per-GPU roofline and `allreduce_ms` (events around the collective); at N = 1 also
+`restarts_small_matrix` = the reference's own size class (1030 x 450): sixteen restarts of a rank one loop at a time against
+all sixteen stepped by one launch (vbnmf_batch_run), aggregate iterations per second.
 
 N > 1 (one process per GPU under torch.distributed.run; a BARE `python bench.py --gpus N` starts those ranks itself as a
 child process -- before torch is imported or the GPU touched -- relays rank 0's line and exits with their status):
@@ -371,6 +373,42 @@ def rank_sweep_sample(M, world, rank, local_rank, barrier, small=False):
             "iterations_total": int(sum(res.nsteps)),
             "best_rank_by_lml": int(res.ranks[int(np.argmax(res.measure["lml"]))]),
             "per_process": [{k: q[k] for k in ("process", "call_s", "layouts_s", "units_s", "exchange_s", "ranks")} for q in rows]}
+
+
+def small_matrix_restarts_sample():
+    """Side measurement (N = 1, rank 0): the reference's OWN size class -- its shipped data set is 1030 x 450 -- where a step is
+    latency bound and the parallelism is the nrun restarts of a rank (reference R/bayesian.R:260-261): 16 restarts of rank 5,
+    400 iterations each, one loop at a time against all sixteen stepped by one launch (vbnmf_batch_run)."""
+    import torch
+    import ccfindr_amd as C
+    from ccfindr_amd import synth
+    X = synth.drop_empty(synth.simulate_data(1030, (150, 150, 150), seed=3, sparse=True))
+    M = C.CountMatrix(X)
+    n, m = X.shape
+    r, B, iters = 5, 16, 400
+    hy = {"aw": 1.0, "bw": 1.0, "ah": 1.0, "bh": 1.0}
+    whs = [synth.random_state(n, m, r, hy, seed=b) for b in range(B)]
+    out = {"workload": f"{n} x {m} counts ({X.nnz} stored), rank {r}, {B} restarts x {iters} iterations, hyper updates on", "dtype": "f64"}
+    kw = dict(Itmax=iters, Tol=0.0, n0=10, dn=1)
+    for label, grid in (("one_at_a_time", None), ("batched", C.batch_grid(B))):
+        engs = [C.VBEngine(M, r, grid=grid) for _ in range(B)]
+        for eng, wh in zip(engs, whs):
+            eng.set_state(wh["lw"], wh["lh"], wh["eh"])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if grid is None:
+            res = [eng.run(hy, **kw) for eng in engs]
+        else:
+            res = C.run_batch(engs, [hy] * B, **kw)
+        dt = time.perf_counter() - t0
+        assert all(o["it"] == iters for o in res)
+        out[label] = {"iterations_per_s": B * iters / dt, "seconds": dt, "lkh_first": res[0]["lkh"]}
+        for eng in engs:
+            eng.close()
+    out["speedup"] = out["batched"]["iterations_per_s"] / out["one_at_a_time"]["iterations_per_s"]
+    out["lkh_rel_diff"] = abs(out["batched"]["lkh_first"] / out["one_at_a_time"]["lkh_first"] - 1)
+    M.close()
+    return out
 
 
 def measure_sweep_traffic(timeout_s=300.0):
@@ -770,6 +808,11 @@ def main():
             rank_sweep = {"error": f"{type(exc).__name__}: {exc}"}
         if rank == 0:
             out["rank_sweep"] = rank_sweep
+    if world == 1 and args.mode == "restarts" and args.rank == 0 and not args.small and not os.environ.get("BENCH_NO_SMALL"):
+        try:
+            out["restarts_small_matrix"] = small_matrix_restarts_sample()
+        except Exception as exc:                                   # noqa: BLE001 -- the headline must still be printed
+            out["restarts_small_matrix"] = {"error": f"{type(exc).__name__}: {exc}"}
     # N > 1, default mode: after the headline (independent restarts, no collective) one C5-shaped cell-partitioned
     # factorisation is run on the same N GPUs, so that the RCCL path of the library is measured on hardware too.  It can
     # only hang where the fabric does, so the headline line is safe behind a watchdog that prints it and leaves.

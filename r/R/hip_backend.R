@@ -31,3 +31,21 @@ vb_iterate_rank_hip <- function(gpu_mat, rank, wh, hyper, bundle, geometry_rank 
   }
   list(wh = vbnmf_state(eng), hyper = hyper, lk0 = lk0, it = it)
 }
+
+# The nrun restarts of ONE rank (reference R/bayesian.R:260-261 runs them one after the other, rank loop inside each) stepped
+# TOGETHER: one engine per restart, made on the grid a batch of B wants, then one call for all their loops (vbnmf_run_batch).
+# `whs` = list of B initial states from vb_init (R/bayesian.R:331), `hyper` the common starting values (:321-326).  On the
+# small matrices ccfindR ships (inst/extdata: 1030 x 450) this is where the GPU's parallelism is: 23 000 -> 160 000
+# iterations per second in all for 32 restarts (profiles/r05_small_concurrent.txt).
+vb_restarts_rank_hip <- function(gpu_mat, rank, whs, hyper, bundle, geometry_rank = 0, device = 0) {
+  B <- length(whs)
+  g <- max(8, (256 %/% B) %/% 8 * 8)
+  vbnmf_set_grid(g, g)
+  engs <- tryCatch(lapply(whs, function(wh) vbnmf_engine_geom(gpu_mat, rank, geometry_rank, wh, device)),
+                   finally = vbnmf_set_grid(0, 0))
+  hy <- matrix(rep(unlist(hyper[c("aw", "bw", "ah", "bh")]), each = B), nrow = B)
+  out <- vbnmf_run_batch(engs, hy, bundle$fudge, bundle$Itmax, bundle$Tol, bundle$hyper.update.n0,
+                         bundle$hyper.update.dn, bundle$hyper.update)
+  lapply(seq_len(B), function(b) list(wh = vbnmf_state(engs[[b]]), hyper = as.list(out$hyper[b, ]), lk0 = out$lk0[b],
+                                      it = out$it[b]))
+}

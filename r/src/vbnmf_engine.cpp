@@ -9,6 +9,7 @@
 //   vbnmf_engine(_geom) / vbnmf_step  one iteration of vb_iterate's loop: wh <- vbnmf_update(...) (R/bayesian.R:339)
 //   vbnmf_state                       the wh members vb_iterate reads after the loop (R/bayesian.R:379-383)
 //   vbnmf_run                         the whole loop (R/bayesian.R:337-352), hyper_update (:2-53) included
+//   vbnmf_run_batch, vbnmf_set_grid   the nrun restarts of a rank (R/bayesian.R:260-261), their loops stepped by one launch
 //   vbnmf_rank_classes                the rank loop of vb_iterate (R/bayesian.R:316) sharing one pair of layouts
 //   mlnmf_*                           nmf_updateR + likelihood (R/factorize.R:2-27, :40-49; called at :195-196)
 //   vbnmf_comm*, vbnmf_engine_part    no counterpart: the reference's only inter-process mechanism is Rmpi::mpi.applyLB over
@@ -143,6 +144,37 @@ Rcpp::List vbnmf_run(SEXP engine, Rcpp::NumericVector hyper, double fudge, int I
                               Rcpp::Named("reason") = reason,
                               Rcpp::Named("hyper") = Rcpp::NumericVector::create(Rcpp::Named("aw") = hy[0],
                                   Rcpp::Named("bw") = hy[1], Rcpp::Named("ah") = hy[2], Rcpp::Named("bh") = hy[3]));
+}
+
+// the restarts of ONE rank stepped together (R/bayesian.R:260-261: lapply(seq_len(nrun), vb_iterate), here rank by rank): one
+// launch steps every engine of the list -- on the small matrices ccfindR ships a single loop cannot fill the GPU.  `engines`
+// were made (with their states) after vbnmf_set_grid(256 %/% B, 256 %/% B); hyper: B x 4 matrix (aw, bw, ah, bh per engine).
+// [[Rcpp::export]]
+void vbnmf_set_grid(int n_wg = 0, int update_blocks = 0) { check(vbnmf_set_engine_grid(n_wg, update_blocks)); }
+
+// [[Rcpp::export]]
+Rcpp::List vbnmf_run_batch(Rcpp::List engines, Rcpp::NumericMatrix hyper, double fudge, int Itmax, double Tol, int n0, int dn,
+                           Rcpp::LogicalVector hyper_update)
+{
+    const int B = engines.size();
+    if (hyper.nrow() != B || hyper.ncol() != 4) Rcpp::stop("vbnmf: hyper must be a B x 4 matrix");
+    std::vector<vbnmf_engine *> es(B);
+    std::vector<double> hy((size_t)B * 4), lk0(B), lkh(B);
+    std::vector<int32_t> it(B), reason(B);
+    for (int b = 0; b < B; b++) { es[b] = eng(engines[b]); for (int q = 0; q < 4; q++) hy[(size_t)b * 4 + q] = hyper(b, q); }
+    int32_t fl[4] = {hyper_update[0], hyper_update[1], hyper_update[2], hyper_update[3]};
+    check(vbnmf_batch_run(es.data(), B, hy.data(), fudge, Itmax, Tol, n0, dn, fl, it.data(), lk0.data(), lkh.data(), reason.data(), nullptr, 0));
+    Rcpp::NumericMatrix out(B, 4);
+    Rcpp::IntegerVector its(B), why(B);
+    Rcpp::NumericVector l0(B), lh(B);
+    for (int b = 0; b < B; b++) {
+        if (reason[b] == 3) Rcpp::stop("Hyperparameter update failed to converge");      // R/bayesian.R:43
+        for (int q = 0; q < 4; q++) out(b, q) = hy[(size_t)b * 4 + q];
+        its[b] = it[b]; why[b] = reason[b]; l0[b] = lk0[b]; lh[b] = lkh[b];
+    }
+    Rcpp::colnames(out) = Rcpp::CharacterVector::create("aw", "bw", "ah", "bh");
+    return Rcpp::List::create(Rcpp::Named("it") = its, Rcpp::Named("lk0") = l0, Rcpp::Named("lkh") = lh,
+                              Rcpp::Named("reason") = why, Rcpp::Named("hyper") = out);
 }
 
 // ---- factorize(): nmf_updateR + likelihood (R/factorize.R:2-27, :40-49)

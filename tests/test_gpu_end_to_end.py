@@ -49,7 +49,7 @@ def test_concurrent_units_give_the_same_result(host_threads):
     kw = dict(ranks=range(2, 8), nrun=3, verbose=0, Tol=1e-6, seed=11, Itmax=1500, unif_stop=False)
     set_host_threads(host_threads)
     try:
-        t0 = time.perf_counter(); a = C.vb_factorize(M, **kw); ta = time.perf_counter() - t0
+        t0 = time.perf_counter(); a = C.vb_factorize(M, batch=1, **kw); ta = time.perf_counter() - t0      # (one unit at a time, the default grids)
         t0 = time.perf_counter(); b = C.vb_factorize(M, concurrent=4, **kw); tb = time.perf_counter() - t0
     finally:
         set_host_threads(0)

@@ -204,3 +204,84 @@ def test_cluster_id_is_one_based_first_maximum():
     assert C.cluster_id(res, 3).tolist() == [2, 1, 3]
     with pytest.raises(IndexError):
         C.cluster_id(res, 4)
+
+
+def test_batched_restarts_driver_equals_the_run_by_run_driver(monkeypatch):
+    """vb_factorize's batched form (bayesian.vb_iterate_batched: the runs of a rank stepped together, rank by rank; the device
+    side is engine.run_batch / vbnmf_batch_run, tests/test_gpu_batch_run.py) against vb_iterate run by run (reference
+    R/bayesian.R:260-261): same records, same best runs, and a run's scan still ends at ITS first rank with a constant column
+    under unif.stop (:373-377) while the other runs go on.  The batch runner here is the host-stepped loop on the numpy engine."""
+    import ccfindr_amd as C
+    from ccfindr_amd import bayesian as B, engine as E
+
+    def host_loop_batch(engines, hypers, Itmax=10000, Tol=1e-5, n0=10, dn=1, flags=(True,) * 4, fudge=C.EPS, history=False):
+        outs = []
+        for eng, hyper in zip(engines, hypers):
+            hyper, lk0, it = dict(hyper), 0.0, 0
+            for it in range(1, Itmax + 1):                                       # R/bayesian.R:337-352
+                lkh, stats = eng.step(hyper, fudge)
+                if it > n0 and it % dn == 0:
+                    hyper = B.hyper_update(list(flags), stats, hyper, Niter=100, Tol=1e-3)
+                if math.isnan(lkh):
+                    break
+                if it > 1 and it > n0 and lkh >= lk0 and abs(1 - lkh / lk0) < Tol:
+                    break
+                lk0 = lkh
+            outs.append({"it": it, "lk0": lk0, "lkh": lkh, "reason": 0, "hyper": hyper, "history": None})
+        return outs
+
+    monkeypatch.setattr(E, "run_batch", host_loop_batch)
+    X = data()
+
+    class UniformInRunTwo(NumpyPhaseEngine):                                     # run 2's rank 3 comes out with a constant column
+        made = 0
+
+        def __init__(self, X, rank):
+            super().__init__(X, rank)
+            UniformInRunTwo.made += 1
+
+        def set_state(self, lw, lh, eh):
+            super().set_state(lw, lh, eh)
+            self.mark = float(lw[0, 0])
+
+        def get_state(self, names=()):
+            s = super().get_state(names)
+            if self.rank == 3 and self.mark == UniformInRunTwo.poison:
+                s["ew"][:, 1] = 0.25
+            return s
+
+    ranks, nrun = [2, 3, 4], 3
+    kw = dict(ranks=ranks, nrun=nrun, verbose=0, initializer="random", Itmax=12, hyper_update=(True,) * 4, gamma_a=1, gamma_b=1, Tol=1e-5,
+              hyper_update_n0=3, hyper_update_dn=1, fudge=None, unif_stop=True, seed=5, device=0)
+    factory = lambda M, r: UniformInRunTwo(X, r)                                 # noqa: E731
+    # the first element of run 2 / rank 3's start identifies that unit whatever the order the units are run in
+    rng = B._bundle_rng({"seed": 5}, 2, 3)
+    UniformInRunTwo.poison = float(B.vb_init(X.shape[0], X.shape[1], X, 3, hyper={"aw": 1.0, "ah": 1.0, "bw": 1.0, "bh": 1.0},
+                                             initializer="random", rng=rng)["lw"][0, 0])
+    results = []
+    for batched in (False, True):
+        bundle = B.make_bundle(X, engine_factory=factory, **kw)
+        bundle["device_loop"] = False
+        bundle["concurrent"] = 1
+        bundle["engines"] = {}
+        B.plan_geometry(bundle, 1)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            vb = B.vb_iterate_batched(bundle, 2) if batched else [B.vb_iterate(irun, bundle) for irun in range(1, nrun + 1)]
+        B._close_engines(bundle)
+        results.append(vb)
+    for a, b in zip(*results):
+        assert a["rdat"] == b["rdat"] and a["nsteps"] == b["nsteps"] and a["hyperp"] == b["hyperp"]
+        for k in a["wdat"]:
+            assert np.array_equal(a["wdat"][k], b["wdat"][k]) and np.array_equal(a["hdat"][k], b["hdat"][k])
+    assert results[1][1]["rdat"][1] == -math.inf and results[1][1]["rdat"][2] == -math.inf      # run 2 stopped at rank 3 ...
+    assert results[1][0]["rdat"][2] > -math.inf and results[1][2]["rdat"][2] > -math.inf        # ... runs 1 and 3 went on
+    # what decides whether vb_factorize batches, and on which grids
+    bundle = B.make_bundle(X, **dict(kw, nrun=5))
+    bundle.update(device_loop=True, concurrent=1)
+    assert B.batch_eligible(bundle, None) == 5 and B.batch_eligible(bundle, 1) == 1 and B.batch_eligible(bundle, 3) == 3
+    assert B.batch_eligible(dict(bundle, nrun=40), None) == 16 and B.batch_eligible(dict(bundle, nrun=1), None) == 1
+    assert B.batch_eligible(dict(bundle, ranks=[2, 17]), None) == 1 and B.batch_eligible(dict(bundle, concurrent=4), None) == 1
+    with pytest.raises(ValueError):
+        B.batch_eligible(dict(bundle, nrun=1), 4)
+    assert E.batch_grid(1) == (256, 256) and E.batch_grid(8) == (32, 32) and E.batch_grid(5) == (48, 48) and E.batch_grid(64) == (8, 8)
