@@ -999,6 +999,8 @@ void vbnmf_engine_destroy(vbnmf_engine *e)
 
 // geometry_rank: the rank whose LDS row size the tiled layouts are cut for (>= r: several ranks of a sweep share one pair
 // of layouts); 0: this rank's class in the matrix's plan (vbnmf_matrix_plan_ranks), its own geometry without one.
+int vbnmf_device_warmup(int32_t device);
+
 int vbnmf_engine_create_geom(const vbnmf_matrix *X, int64_t cb, int64_t ce, int64_t m_global, int32_t r, int32_t geometry_rank,
                              int32_t device, vbnmf_engine **out)
 {
@@ -1042,21 +1044,15 @@ int vbnmf_engine_create_geom(const vbnmf_matrix *X, int64_t cb, int64_t ce, int6
     if (int rc = sweep_workgroups(device, e->partitioned, e->n_wg)) { delete e; return rc; }
     if (!e->partitioned && tl_grid_nwg > 0) e->n_wg = std::min(e->n_wg, tl_grid_nwg);
     int rc = VBNMF_OK;
-    auto bail = [&](int code) { vbnmf_engine_destroy(e); return code; };
-    {
-        // The engine's stream first: everything that initialises the engine's own buffers below is queued ON it
-        // (hipMemsetAsync), so it is ordered with the engine's kernels.  A plain hipMemset goes to the device's null stream,
-        // which this non-blocking stream does not wait for, and may return before the fill has run: with several host threads
-        // creating engines side by side (vb_factorize(concurrent=K)) a fill queued behind the other threads' null-stream work
-        // could land AFTER the engine's first kernels had written the buffer -- zeroed block partials, a different trajectory
-        // (seen once in round 5, tests/test_gpu_end_to_end.py::test_concurrent_units_give_the_same_result).
-        hipError_t hs;
-        if ((hs = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)) != hipSuccess ||
-            (hs = hipEventCreate(&e->ev0)) != hipSuccess || (hs = hipEventCreate(&e->ev1)) != hipSuccess ||
-            (hs = hipEventCreate(&e->ev2)) != hipSuccess || (hs = hipEventCreate(&e->ev3)) != hipSuccess)
-            return bail(fail(VBNMF_ERR_HIP, "engine setup failed: %s", hipGetErrorString(hs)));
-        e->own_stream = true;
-    }
+    // This process's FIRST use of the device (HIP context, first allocation, code object: 0.1-0.15 s, once) runs on a helper
+    // thread beside the host's cut of the layouts and is waited for where the first upload needs it (a failure there
+    // resurfaces at that upload).  Later engines find the device warm and start no thread.
+    static std::atomic<bool> warm_started[16];
+    std::thread warm;
+    std::mutex warm_mu;
+    if (device < 16 && !warm_started[device].exchange(true)) warm = std::thread([device] { (void)vbnmf_device_warmup(device); });
+    auto join_warm = [&] { std::lock_guard<std::mutex> g(warm_mu); if (warm.joinable()) warm.join(); };
+    auto bail = [&](int code) { join_warm(); vbnmf_engine_destroy(e); return code; };
 
     try {
         std::vector<int32_t> part_order;                         // a partition orders its own cells (both sides alike)
@@ -1068,7 +1064,7 @@ int vbnmf_engine_create_geom(const vbnmf_matrix *X, int64_t cb, int64_t ce, int6
         // thread, the gene side here.  Each cut is memory-bound well before it uses all host threads, and a side's upload
         // (200 MB of pageable memory at the headline size) runs beside the other side's cut.  Engine creation at the headline
         // size: 0.41 -> 0.3 s on the GPU box (profiles/r05_setup_times.txt).  VBNMF_SERIAL_SIDES=1: one after the other.
-        mark("stream, workgroups");
+        mark("start");
         if (cb == 0 && ce == X->M.m && !X->M.shell) (void)X->M.cell_order();          // (both sides start from it: formed once, here)
         mark("cell order");
         auto do_side = [&](int side) -> int {
@@ -1089,6 +1085,7 @@ int vbnmf_engine_create_geom(const vbnmf_matrix *X, int64_t cb, int64_t ce, int6
                 src = build_layout(X->M, cb, ce, side, lp, &part_order, own);
             }
             mark(side == 0 ? "gene side cut" : "cell side cut");
+            join_warm();
             if (!src) src = upload_side(*L, e->R, device, shared ? X : nullptr, side == 0 ? e->A : e->B);
             mark(side == 0 ? "gene side uploaded" : "cell side uploaded");
             Ls[side] = L;
@@ -1146,8 +1143,26 @@ int vbnmf_engine_create_geom(const vbnmf_matrix *X, int64_t cb, int64_t ce, int6
     } catch (const std::bad_alloc &) {
         rc = fail(VBNMF_ERR_OOM, "out of host memory building the tiled layout");
     }
+    join_warm();
     if (rc) return bail(rc);
     mark("both sides, update table");
+    {
+        // The engine's stream, before the first fill: everything that initialises the engine's own buffers below is queued ON it
+        // (hipMemsetAsync), so it is ordered with the engine's kernels.  A plain hipMemset goes to the device's null stream,
+        // which this non-blocking stream does not wait for, and may return before the fill has run: with several host threads
+        // creating engines side by side (vb_factorize(concurrent=K)) a fill queued behind the other threads' null-stream work
+        // could land AFTER the engine's first kernels had written the buffer -- zeroed block partials, a different trajectory
+        // (seen once in round 5, tests/test_gpu_end_to_end.py::test_concurrent_units_give_the_same_result).
+        // (Created HERE and not at the top: this process's first use of the device -- 0.1 s of HIP start-up -- then happens on the
+        // cell side's thread, at its upload, beside the gene side's cut, instead of in front of both.)
+        hipError_t hs;
+        if ((hs = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)) != hipSuccess ||
+            (hs = hipEventCreate(&e->ev0)) != hipSuccess || (hs = hipEventCreate(&e->ev1)) != hipSuccess ||
+            (hs = hipEventCreate(&e->ev2)) != hipSuccess || (hs = hipEventCreate(&e->ev3)) != hipSuccess)
+            return bail(fail(VBNMF_ERR_HIP, "engine setup failed: %s", hipGetErrorString(hs)));
+        e->own_stream = true;
+    }
+
     if (!e->cell_perm.empty() && (rc = dev_upload(&e->d_perm, e->cell_perm))) return bail(rc);
     e->lgx = (cb == 0 && ce == X->M.m) ? X->lgx : sum_lgamma_x1(X->M, cb, ce);
     if (cb == 0 && ce == X->M.m) {                    // whole matrix: formed once per matrix, not per engine (a pass over X)
