@@ -6,7 +6,7 @@ libvbnmf_hip.so (hand-written HIP for gfx950) behind the C ABI of include/vbnmf.
 no CPU fallback.
 """
 from ._native import LIB_PATH, MAX_RANK, VBNMFError, load  # noqa: F401
-from .engine import EPS, Communicator, CountMatrix, VBEngine, batch_grid, run_batch  # noqa: F401
+from .engine import EPS, Communicator, CountMatrix, VBEngine, batch_grid, run_batch, run_batch_ml  # noqa: F401
 from .bayesian import (VBResult, hyper_update, vb_factorize, vb_init, vb_iterate,  # noqa: F401
                        vbnmf_update)
 

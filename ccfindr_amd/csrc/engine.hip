@@ -2205,6 +2205,254 @@ int vbnmf_batch_run(vbnmf_engine **engs, int32_t count, double *hyper, double fu
     return restore(VBNMF_OK);
 }
 
+}  // extern "C"
+
+namespace {
+
+template <int R, bool WIDE, bool LOGTERM>
+int launch_sweep1_batch_t(vbnmf_engine *e, const SweepSide *jobs, int B)
+{
+    constexpr int NT = sweep_threads(R);
+    static std::atomic<bool> attr_set[16];
+    const void *fn = (const void *)k_sweep1_batch<R, WIDE, LOGTERM, NT>;
+    if (e->device >= 16 || !attr_set[e->device].load(std::memory_order_acquire)) {
+        if (int rc = prepare_sweep_kernel(fn)) return rc;
+        if (e->device < 16) attr_set[e->device].store(true, std::memory_order_release);
+    }
+    hipLaunchKernelGGL((k_sweep1_batch<R, WIDE, LOGTERM, NT>), dim3((unsigned)e->n_wg, (unsigned)B), dim3(NT), e->lds_bytes, e->stream, jobs);
+    HIPCHECK(hipGetLastError());
+    return VBNMF_OK;
+}
+
+int launch_sweep1_batch(vbnmf_engine *e, const SweepSide *jobs, int B, bool logterm)
+{
+    switch (e->R) {
+#define X(RR) case RR: return e->wide ? (logterm ? launch_sweep1_batch_t<RR, true, true>(e, jobs, B) : launch_sweep1_batch_t<RR, true, false>(e, jobs, B)) \
+                                      : (logterm ? launch_sweep1_batch_t<RR, false, true>(e, jobs, B) : launch_sweep1_batch_t<RR, false, false>(e, jobs, B));
+        VBNMF_FOR_EACH_R_BATCH(X)
+#undef X
+        default: return fail(VBNMF_ERR_BAD_ARG, "a batch serves padded ranks up to %d (this engine: %d)", kBatchMaxPaddedRank, e->R);
+    }
+}
+
+int launch_ml_update_batch(vbnmf_engine *e, const MlUpdJob *jobs, int B)
+{
+    switch (e->R) {
+#define X(RR) case RR: hipLaunchKernelGGL((k_ml_update_batch<RR>), dim3((unsigned)e->ub, (unsigned)B), dim3(kUpdateThreads), 0, e->stream, jobs); break;
+        VBNMF_FOR_EACH_R_BATCH(X)
+#undef X
+        default: return fail(VBNMF_ERR_BAD_ARG, "a batch serves padded ranks up to %d (this engine: %d)", kBatchMaxPaddedRank, e->R);
+    }
+    HIPCHECK(hipGetLastError());
+    return VBNMF_OK;
+}
+
+MlFold batch_ml_fold(const vbnmf_engine *e, int t, bool hist, const double *bpH_prev)
+{
+    MlFold f{};
+    f.prev = e->ctl2 + ((t - 1) & 1); f.next = e->ctl2 + (t & 1);
+    f.bpH_prev = bpH_prev;
+    f.epart = e->epart + e->n_wg; f.nepart = (int64_t)e->n_wg;
+    f.xlx = e->xlx; f.n = (double)e->n; f.m = (double)e->m;
+    f.history = hist ? e->h_hist_dev : nullptr; f.out_host = e->h_out_dev;
+    f.do_control = t > 1 ? 1 : 0;
+    return f;
+}
+
+}  // namespace
+
+extern "C" {
+
+// The device-driven ML-NMF loops (vbnmf_engine_ml_run; factorize() under criterion = 'likelihood', reference
+// R/factorize.R:194-213) of `count` engines of ONE rank on ONE matrix -- the `nrun` restarts factorize() makes of every rank
+// (R/factorize.R:181; its default is nrun = 20) -- stepped together: four launches per step for the whole batch.  Per engine
+// the results are those of vbnmf_engine_ml_run on it alone, bit for bit.  it_out, lk_out, reason_out: [count]; history (or
+// NULL): [count][history_rows], history_rows >= max_it.  Engines as for vbnmf_batch_run, their states set by ml_set_state.
+int vbnmf_batch_ml_run(vbnmf_engine **engs, int32_t count, int32_t prior, double gamma_a, double gamma_b, int32_t max_it, double tol,
+                       int32_t *it_out, double *lk_out, int32_t *reason_out, double *history, int64_t history_rows)
+{
+    if (!engs) return fail(VBNMF_ERR_BAD_ARG, "NULL argument");
+    if (count < 1 || count > kBatchMax) return fail(VBNMF_ERR_BAD_ARG, "a batch holds 1 to %d engines", kBatchMax);
+    if (max_it < 1) return fail(VBNMF_ERR_BAD_ARG, "max_it must be >= 1");
+    if (history && history_rows < max_it) return fail(VBNMF_ERR_BAD_ARG, "history needs max_it doubles per engine");
+    vbnmf_engine *e0 = engs[0];
+    if (!e0) return fail(VBNMF_ERR_BAD_ARG, "engine handle is NULL");
+    const int B = count;
+    const double eps = 2.220446049250313e-16;
+    for (int b = 0; b < B; b++) {
+        vbnmf_engine *e = engs[b];
+        if (!e) return fail(VBNMF_ERR_BAD_ARG, "engine handle is NULL");
+        for (int q = 0; q < b; q++) if (engs[q] == e) return fail(VBNMF_ERR_BAD_ARG, "the same engine twice in a batch");
+        if (int rc = use_device(e)) return rc;
+        if (e->partitioned || e->comm || !e->fold || !e->bpH_alt || e->R > kBatchMaxPaddedRank)
+            return fail(VBNMF_ERR_STATE, "a batch takes unpartitioned engines with the control step folded in and padded rank <= %d", kBatchMaxPaddedRank);
+        if (e->device != e0->device || e->n != e0->n || e->m != e0->m || e->r != e0->r || e->R != e0->R || e->n_wg != e0->n_wg || e->ub != e0->ub ||
+            e->NT != e0->NT || e->wide != e0->wide || e->lds_bytes != e0->lds_bytes || e->A.n_slices != e0->A.n_slices || e->B.n_slices != e0->B.n_slices)
+            return fail(VBNMF_ERR_STATE, "the engines of a batch must be of one rank on one matrix (same layouts and grids)");
+        if (!e->ml_ready) return fail(VBNMF_ERR_STATE, "batch ML run before ml_set_state");
+        if (history) { if (int rc = ensure_history(e, (size_t)max_it)) return rc; }
+    }
+    hipStream_t S = e0->stream;
+    for (int b = 1; b < B; b++) HIPCHECK(hipStreamSynchronize(engs[b]->stream));
+
+    const bool hist = history != nullptr;
+    static const int stage_allowed = [] { const char *v = getenv("VBNMF_NO_STAGE_IDS"); return (v && v[0] == '1') ? 0 : 1; }();
+    // jobs: the H update's of step 1, of the odd and of the even steps; the W update's and the two sweeps' by parity
+    std::vector<MlUpdJob> jh((size_t)3 * B), jw((size_t)2 * B);
+    std::vector<SweepSide> jg((size_t)2 * B), jc((size_t)2 * B);
+    std::vector<hipStream_t> own(B);
+    std::vector<bool> timing(B);
+    for (int b = 0; b < B; b++) {
+        vbnmf_engine *e = engs[b];
+        own[b] = e->stream; timing[b] = e->timing;
+        e->timing = false; e->ev_recorded = false; e->ev2_recorded = false;
+        double *Ht[2] = {e->bpH, e->bpH_alt};                                    // [0]: the latest table as the run starts
+        for (int v = 0; v < 3; v++) {
+            const int t = v == 0 ? 1 : (v == 1 ? 3 : 2);
+            MlUpdJob &J = jh[(size_t)v * B + b];
+            J.part = e->B.part; J.inv_ptr = e->B.inv_ptr; J.inv_task = e->B.inv_task; J.nmaj = e->m;
+            J.other_bp = e->bpW; J.f = e->lh; J.bp = Ht[t & 1]; J.stop = nullptr;
+            J.ga = gamma_a; J.gb = gamma_b; J.eps = eps;
+            J.r = e->r; J.other_nb = e->ub; J.prior = prior;
+            J.stage_ids = stage_allowed && e->B.n_tasks >= (int64_t)256 * e->ub ? 1 : 0;
+            J.fold = batch_ml_fold(e, t, hist, Ht[(t - 1) & 1]);
+        }
+        e->run_active = true;
+        for (int par = 0; par < 2; par++) {                                      // step t of parity par = t & 1
+            const int32_t *stop = &(e->ctl2 + par)->stop;                        // what that step's H update left
+            MlUpdJob &J = jw[(size_t)par * B + b];
+            J.part = e->A.part; J.inv_ptr = e->A.inv_ptr; J.inv_task = e->A.inv_task; J.nmaj = e->n;
+            J.other_bp = Ht[par]; J.f = e->lw; J.bp = e->bpW; J.stop = stop;
+            J.ga = gamma_a; J.gb = gamma_b; J.eps = eps;
+            J.r = e->r; J.other_nb = e->ub; J.prior = prior;
+            J.stage_ids = stage_allowed && e->A.n_tasks >= (int64_t)256 * e->ub ? 1 : 0;
+            J.fold = MlFold{};
+            e->stop_ptr = stop;
+            SweepSide g = sweep_side_args(e, e->A, true, e->epart);
+            g.logterm = 0;
+            SweepSide c = sweep_side_args(e, e->B, false, e->epart + e->n_wg);
+            c.logterm = 1;
+            jg[(size_t)par * B + b] = g; jc[(size_t)par * B + b] = c;
+        }
+        e->stop_ptr = nullptr;
+    }
+    MlUpdJob *d_jh = nullptr, *d_jw = nullptr;
+    SweepSide *d_jg = nullptr, *d_jc = nullptr;
+    auto restore = [&](int rc) {
+        for (int b = 0; b < B; b++) {
+            vbnmf_engine *e = engs[b];
+            e->stream = own[b];
+            e->run_active = false; e->timing = timing[b]; e->stop_ptr = nullptr;
+            e->seq = 0.0; e->h_out[7] = 0.0;
+        }
+        dev_free(d_jh); dev_free(d_jw); dev_free(d_jg); dev_free(d_jc);
+        return rc;
+    };
+    if (int rc = dev_upload(&d_jh, jh)) return restore(rc);
+    if (int rc = dev_upload(&d_jw, jw)) return restore(rc);
+    if (int rc = dev_upload(&d_jg, jg)) return restore(rc);
+    if (int rc = dev_upload(&d_jc, jc)) return restore(rc);
+    for (int b = 0; b < B; b++) {
+        vbnmf_engine *e = engs[b];
+        LoopCtl c{};
+        c.lk0 = -INFINITY;                                                        // lkold <- -Inf (R/factorize.R:193)
+        c.tol = tol; c.max_it = max_it;
+        hipLaunchKernelGGL(k_ctl_init, dim3(1), dim3(1), 0, S, e->ctl2, c);
+        e->fold_step = 0;
+        volatile double *ho = e->h_out;
+        ho[5] = 0.0; ho[6] = 0.0; ho[7] = 0.0;
+        e->stream = S;
+    }
+    {
+        hipError_t he = hipGetLastError();
+        if (he != hipSuccess) { (void)hipStreamSynchronize(S); return restore(fail(VBNMF_ERR_HIP, "loading the loop control blocks failed: %s", hipGetErrorString(he))); }
+    }
+    int queued = 0;
+    auto queue_step = [&]() -> int {
+        const int t = queued + 1;
+        const int v = t == 1 ? 0 : ((t & 1) ? 1 : 2), par = t & 1;
+        if (int rc = launch_ml_update_batch(e0, d_jh + (size_t)v * B, B)) return rc;           // H <- , the previous step's control folded in
+        for (int b = 0; b < B; b++) { vbnmf_engine *e = engs[b]; std::swap(e->bpH, e->bpH_alt); e->fold_step = t; }
+        if (int rc = launch_sweep1_batch(e0, d_jg + (size_t)par * B, B, false)) return rc;     // gene side on (w, h_new)
+        if (int rc = launch_ml_update_batch(e0, d_jw + (size_t)par * B, B)) return rc;         // W <-
+        if (int rc = launch_sweep1_batch(e0, d_jc + (size_t)par * B, B, true)) return rc;      // cell side on (h_new, w_new): next step's statistics + sum x log(wh)
+        if (t == max_it) {
+            for (int b = 0; b < B; b++) {
+                vbnmf_engine *e = engs[b];
+                MlFold g = batch_ml_fold(e, t + 1, hist, e->bpH);
+                g.do_control = 1; g.control_only = 1;
+                if (int rc = launch_ml_update(e, false, prior, gamma_a, gamma_b, eps, &g)) return rc;
+            }
+        }
+        queued++;
+        return VBNMF_OK;
+    };
+    auto queue_batch = [&]() -> int {
+        for (int q = 0; q < 8 && queued < max_it; q++) if (int rc = queue_step()) return rc;
+        return VBNMF_OK;
+    };
+    auto fail_out = [&](int rc) {
+        std::string msg = last_error_cstr();
+        if (e0->poisoned) { for (int b = 0; b < B; b++) { engs[b]->poisoned = true; engs[b]->stream = own[b]; } return fail(rc, "%s", msg.c_str()); }
+        (void)hipStreamSynchronize(S);
+        restore(rc);
+        return fail(rc, "%s", msg.c_str());
+    };
+    if (int rc = queue_batch()) return fail_out(rc);
+    if (int rc = queue_batch()) return fail_out(rc);
+    const double limit = wait_timeout_s();
+    for (int bt = 0;; bt++) {
+        const int target = (int)std::min<int64_t>((int64_t)(bt + 1) * 8, max_it);
+        const auto t0 = std::chrono::steady_clock::now();
+        bool all_stopped = false;
+        for (long spins = 1;; spins++) {
+            bool reached = true;
+            all_stopped = true;
+            for (int b = 0; b < B; b++) {
+                volatile double *ho = engs[b]->h_out;
+                const bool stopped = ho[6] != 0.0;
+                all_stopped = all_stopped && stopped;
+                reached = reached && (stopped || (int)ho[7] >= target);
+            }
+            if (reached) break;
+            if ((spins & 0xFFFF) == 0) {
+                const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                if (waited > limit) {
+                    e0->poisoned = true;
+                    return fail_out(fail(VBNMF_ERR_HIP, "timed out after %.1f s (VBNMF_WAIT_TIMEOUT_S) waiting for step %d of a batch's ML loop (%d queued)", waited, target, queued));
+                }
+                hipError_t q = hipStreamQuery(S);
+                if (q != hipSuccess && q != hipErrorNotReady) return fail_out(fail(VBNMF_ERR_HIP, "the batch's loop failed on the device: %s", hipGetErrorString(q)));
+                if (q == hipSuccess) {
+                    bool ok = true;
+                    const int expect = queued - (queued < max_it ? 1 : 0);
+                    for (int b = 0; b < B; b++) { volatile double *ho = engs[b]->h_out; ok = ok && (ho[6] != 0.0 || (int)ho[7] >= std::min(target, expect)); }
+                    if (!ok) return fail_out(fail(VBNMF_ERR_HIP, "the device went idle before the queued steps of the batch finished"));
+                }
+            }
+        }
+        if (all_stopped || target >= max_it) break;
+        if (int rc = queue_batch()) return fail_out(rc);
+    }
+    {
+        hipError_t he = hipStreamSynchronize(S);
+        if (he != hipSuccess) return restore(fail(VBNMF_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(he)));
+    }
+    for (int b = 0; b < B; b++) {
+        vbnmf_engine *e = engs[b];
+        const int it = (int)e->h_out[5];
+        if (it_out) it_out[b] = it;
+        if (lk_out) lk_out[b] = e->h_out[0];
+        if (reason_out) reason_out[b] = (int)e->h_out[6];
+        if (history && it > 0) std::memcpy(history + (size_t)b * (size_t)history_rows, e->h_hist, (size_t)it * sizeof(double));
+    }
+    std::vector<double> lk_last(B);
+    for (int b = 0; b < B; b++) lk_last[b] = engs[b]->h_out[0];
+    const int rc = restore(VBNMF_OK);
+    for (int b = 0; b < B; b++) engs[b]->h_out[0] = lk_last[b];                   // ml_likelihood() keeps answering for the pair held now
+    return rc;
+}
+
 // ---------------------------------------------------------------- communicators (comm.h)
 int vbnmf_comm_unique_id(void *id, int64_t bytes)
 {

@@ -35,10 +35,10 @@ struct MlFold {
 };
 
 template <int R>
-__global__ __launch_bounds__(kUpdateThreads) void k_ml_update(
+__device__ __forceinline__ void ml_update_body(
     const double *__restrict__ part, const int32_t *__restrict__ inv_ptr, const uint32_t *__restrict__ inv_task,
     int64_t nmaj, int r, const double *__restrict__ other_bp, int other_nb, int prior, double ga, double gb, double eps,
-    double *__restrict__ f, double *__restrict__ bp, const int32_t *__restrict__ stop, const MlFold fold, int stage_ids)
+    double *__restrict__ f, double *__restrict__ bp, const int32_t *__restrict__ stop, const MlFold &fold, int stage_ids)
 {
     constexpr int RB = kUpdateThreads / R;       // majors per pass
     __shared__ double s_other[R + 2];
@@ -151,6 +151,47 @@ __global__ __launch_bounds__(kUpdateThreads) void k_ml_update(
     double *o = bp + (size_t)blockIdx.x * (R + 2);
     if (t < R) o[t] = s_e[t];
     if (t == 0) { o[R] = 0.0; o[R + 1] = 0.0; }
+}
+
+template <int R>
+__global__ __launch_bounds__(kUpdateThreads) void k_ml_update(
+    const double *__restrict__ part, const int32_t *__restrict__ inv_ptr, const uint32_t *__restrict__ inv_task,
+    int64_t nmaj, int r, const double *__restrict__ other_bp, int other_nb, int prior, double ga, double gb, double eps,
+    double *__restrict__ f, double *__restrict__ bp, const int32_t *__restrict__ stop, const MlFold fold, int stage_ids)
+{
+    ml_update_body<R>(part, inv_ptr, inv_task, nmaj, r, other_bp, other_nb, prior, ga, gb, eps, f, bp, stop, fold, stage_ids);
+}
+
+// A BATCH of engines stepped by one launch (kernels.h: k_update2_batch; here the restarts of factorize(), reference
+// R/factorize.R:181: `for(irun in seq_len(nrun))`): blockIdx.y picks the engine's argument block, the body is the single engine's.
+struct MlUpdJob {
+    const double *part;
+    const int32_t *inv_ptr;
+    const uint32_t *inv_task;
+    int64_t nmaj;
+    const double *other_bp;
+    double *f, *bp;
+    const int32_t *stop;
+    double ga, gb, eps;
+    int32_t r, other_nb, prior, stage_ids;
+    MlFold fold;
+};
+
+template <int R>
+__global__ __launch_bounds__(kUpdateThreads) void k_ml_update_batch(const MlUpdJob *__restrict__ jobs)
+{
+    const MlUpdJob J = jobs[blockIdx.y];
+    ml_update_body<R>(J.part, J.inv_ptr, J.inv_task, J.nmaj, J.r, J.other_bp, J.other_nb, J.prior, J.ga, J.gb, J.eps, J.f, J.bp, J.stop,
+                      J.fold, J.stage_ids);
+}
+
+template <int R, bool WIDE, bool LOGTERM, int NT>
+__global__ __launch_bounds__(NT) void k_sweep1_batch(const SweepSide *__restrict__ jobs)
+{
+    extern __shared__ double2 ldsG[];
+    const SweepSide S = jobs[blockIdx.y];
+    if (S.stop && *S.stop) return;
+    sweep_side<R, WIDE, LOGTERM, NT, LOGTERM ? 2 : 0, 1>(S, ldsG);
 }
 
 // Likelihood (R/factorize.R:40-49).  One block.  out = [lk, sum x log(wh), sum(wh), 0, 0], out_host[7] = seq.

@@ -519,6 +519,25 @@ def run_batch(engines, hypers, Itmax=10000, Tol=1e-5, n0=10, dn=1, flags=(True,)
              "history": hist[b, :it[b]].copy() if history else None} for b in range(B)]
 
 
+def run_batch_ml(engines, Itmax=10000, Tol=1e-5, prior=False, gamma_a=1.0, gamma_b=1.0, history=False):
+    """The ML-NMF loops (``VBEngine.ml_run``) of several engines of ONE rank on ONE ``CountMatrix`` -- the ``nrun`` restarts
+    ``factorize`` makes of a rank, reference R/factorize.R:181 -- stepped together (``vbnmf_batch_ml_run``).  Every engine has
+    had ``ml_set_state``.  Returns one ``ml_run`` result per engine, bit for bit what ``ml_run`` gives on that engine alone."""
+    B = len(engines)
+    if B < 1:
+        raise ValueError("an empty batch")
+    lib = engines[0]._lib
+    hs = (ctypes.c_void_p * B)(*(e._h for e in engines))
+    it = np.zeros(B, dtype=np.int32); reason = np.zeros(B, dtype=np.int32)
+    lk = np.zeros(B)
+    hist = np.zeros((B, int(Itmax))) if history else None
+    N.check(lib.vbnmf_batch_ml_run(hs, B, int(bool(prior)), float(gamma_a), float(gamma_b), int(Itmax), float(Tol),
+                                   it.ctypes.data_as(N.c_int32_p), N.dptr(lk), reason.ctypes.data_as(N.c_int32_p),
+                                   N.dptr(hist), int(Itmax) if history else 0))
+    return [{"it": int(it[b]), "lk": float(lk[b]), "reason": int(reason[b]),
+             "history": hist[b, :it[b]].copy() if history else None} for b in range(B)]
+
+
 def _run_outputs(Itmax, history):
     return (ctypes.c_int32(), ctypes.c_int32(), ctypes.c_double(), ctypes.c_double(),
             np.zeros((int(Itmax), 9)) if history else None)

@@ -6,6 +6,7 @@ reference's, line by line.  No CPU fallback: without the HIP library every call 
 from __future__ import annotations
 
 import ctypes
+import os
 import sys
 from dataclasses import dataclass, field
 
@@ -13,6 +14,8 @@ import numpy as np
 
 from . import _native as N
 from .engine import CountMatrix, VBEngine
+
+BATCH_MAX_RANK = 16          # ranks the batch kernels are built for (csrc/engine.hip: kBatchMaxPaddedRank)
 
 # Above this many cell pairs the O(m^2) connectivity vector (R/factorize.R:51-60) is not formed: dispersion
 # and cophenetic are NaN (the reference would try to allocate it).
@@ -123,14 +126,17 @@ class MLResult:
 
 def factorize(mat, ranks=2, nrun=20, randomize=False, nsmpl=1, verbose=2, progress_bar=True, Itmax=10000,
               ncnn_step=40, criterion="likelihood", linkage="average", Tol=1e-5, store_connectivity=False,
-              seed=None, device=0, engine_factory=None, device_loop=True):
+              seed=None, device=0, engine_factory=None, device_loop=True, batch=None):
     """Maximum-likelihood NMF of a count matrix on the MI355X engine; reference R/factorize.R:140-320.
 
     ``mat``: genes x cells counts (dense array, scipy sparse, or ``CountMatrix``).  ``seed`` seeds the numpy
     Generator behind ``init`` and the ``randomize`` permutations.  ``engine_factory(count_matrix, rank)`` replaces
     the engine constructor (the CPU tests of this loop pass a stand-in).  ``device_loop``: under
     ``criterion='likelihood'`` (and ``verbose < 3``) the inner loop (:194-213) runs on the device
-    (``vbnmf_engine_ml_run``) instead of one call per iteration.  Returns ``MLResult``.
+    (``vbnmf_engine_ml_run``) instead of one call per iteration.  ``batch``: how many of a rank's ``nrun`` restarts
+    (:181) are stepped by ONE launch (``engine.run_batch_ml``; 1: one at a time; None: up to 16 where the device loop runs,
+    the rank is at most 16 and the matrix holds up to 2e7 stored entries) -- on a small matrix one loop cannot fill the GPU.
+    The restarts draw their starts from the same stream in the same order either way.  Returns ``MLResult``.
     """
     del progress_bar
     if isinstance(mat, CountMatrix):
@@ -175,17 +181,43 @@ def factorize(mat, ranks=2, nrun=20, randomize=False, nsmpl=1, verbose=2, progre
                 Ms.host = A
             else:
                 Ms = M
-            eng = engine_factory(Ms, rank) if engine_factory else VBEngine(Ms, rank, device=device)
+            # the restarts of this rank stepped `nb` at a time by one launch (engine.run_batch_ml), or one engine for all of them
+            nb = 1
+            if (engine_factory is None and device_loop and criterion == "likelihood" and verbose < 3 and nrun > 1 and rank <= BATCH_MAX_RANK
+                    and (batch is None or int(batch) > 1) and os.environ.get("VBNMF_NO_CONTROL_FOLD", "0") != "1"):
+                nb = min(nrun, 16 if batch is None else int(batch), 64) if (batch is not None or Ms.nnz <= 20_000_000) else 1
+            elif batch is not None and int(batch) > 1:
+                raise ValueError("batch > 1 needs nrun > 1, rank <= %d, criterion 'likelihood', the device loop and the library's own engines" % BATCH_MAX_RANK)
+            if nb > 1:
+                from .engine import batch_grid, run_batch_ml
+                batch_engines = [VBEngine(Ms, rank, device=device, grid=batch_grid(nb)) for _ in range(nb)]
+                eng = batch_engines[0]
+            else:
+                batch_engines = None
+                eng = engine_factory(Ms, rank) if engine_factory else VBEngine(Ms, rank, device=device)
             rmax, wmax, hmax, disp, steps = -np.inf, None, None, np.nan, []
+            ahead = {}                                                             # batched: results of runs already stepped
             try:
                 for irun in range(1, nrun + 1):
                     if verbose >= 2:
                         say(f"Rnd.sample # {ismpl} , run # {irun} :" if randomize else f"Run # {irun} :")
-                    wh = init(nrow, ncol, rank, rng)                               # :192
-                    eng.ml_set_state(wh["ew"], wh["eh"])
+                    if batch_engines is not None:
+                        if irun not in ahead:                                      # this run opens a chunk: draw the chunk's starts in run
+                            chunk = list(range(irun, min(nrun, irun + nb - 1) + 1))                 # order (:192), step them together
+                            for slot, jrun in enumerate(chunk):
+                                whj = init(nrow, ncol, rank, rng)
+                                batch_engines[slot].ml_set_state(whj["ew"], whj["eh"])
+                            for slot, (jrun, res) in enumerate(zip(chunk, run_batch_ml(batch_engines[:len(chunk)], Itmax=Itmax, Tol=Tol))):
+                                ahead[jrun] = (batch_engines[slot], res)
+                        eng, run = ahead.pop(irun)
+                    else:
+                        wh = init(nrow, ncol, rank, rng)                           # :192
+                        eng.ml_set_state(wh["ew"], wh["eh"])
                     zstep, lkold, cid0, lk0, it = 0, -np.inf, None, np.nan, 0
                     on_device = device_loop and criterion == "likelihood" and verbose < 3 and hasattr(eng, "ml_run")
-                    if on_device:                                                  # the loop below, driven by the device
+                    if batch_engines is not None:
+                        it, lk0 = run["it"], run["lk"]
+                    elif on_device:                                                # the loop below, driven by the device
                         run = eng.ml_run(Itmax=Itmax, Tol=Tol)
                         it, lk0 = run["it"], run["lk"]
                     for it in (() if on_device else range(1, Itmax + 1)):          # :196
@@ -220,7 +252,8 @@ def factorize(mat, ranks=2, nrun=20, randomize=False, nsmpl=1, verbose=2, progre
                     if (irun == 1 or lk0 > rmax) and not np.isnan(lk0):            # :223
                         rmax, wmax, hmax = lk0, st["ew"], st["eh"]
             finally:
-                eng.close()
+                for be in (batch_engines if batch_engines is not None else [eng]):
+                    be.close()
                 if randomize:
                     Ms.close()
             coph = cophenet(conav / nrun, ncol, method=linkage) if pairs_ok else np.nan    # :230

@@ -392,6 +392,15 @@ int vbnmf_engine_ml_step(vbnmf_engine *e, int32_t prior, double gamma_a, double 
 int vbnmf_engine_ml_run(vbnmf_engine *e, int32_t prior, double gamma_a, double gamma_b, int32_t max_it,
                         double tol, int32_t *it, double *lk, int32_t *reason, double *history,
                         int64_t history_rows);
+
+/* The `nrun` restarts factorize() makes of every rank (`for(irun in seq_len(nrun))`, R/factorize.R:181; nrun defaults to 20),
+ * their device-driven loops (vbnmf_engine_ml_run: R/factorize.R:194-213 under criterion = 'likelihood') stepped together: four
+ * launches per step for the whole batch, every engine following its own control block.  Per engine the results are those of
+ * vbnmf_engine_ml_run on it alone, bit for bit.  Engines as for vbnmf_batch_run (one rank, one matrix handle, rank <= 16,
+ * count <= 64, grids from vbnmf_set_engine_grid), their states set by vbnmf_engine_ml_set_state.  it_out, lk_out, reason_out:
+ * [count] (any may be NULL); history (or NULL): [count][history_rows], history_rows >= max_it. */
+int vbnmf_batch_ml_run(vbnmf_engine **engines, int32_t count, int32_t prior, double gamma_a, double gamma_b, int32_t max_it,
+                       double tol, int32_t *it_out, double *lk_out, int32_t *reason_out, double *history, int64_t history_rows);
 int vbnmf_engine_ml_likelihood(vbnmf_engine *e, double *lk);
 int vbnmf_engine_ml_get_state(vbnmf_engine *e, double *w, double *h);
 /* Stateless forms of the same step: nmf_updateR(x, w, h, n, m, r, prior, gamma.a, gamma.b)

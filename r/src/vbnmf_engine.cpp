@@ -198,6 +198,22 @@ Rcpp::List mlnmf_run(SEXP engine, int Itmax, double Tol, bool prior = false, dou
     check(vbnmf_engine_ml_run(eng(engine), prior ? 1 : 0, gamma_a, gamma_b, Itmax, Tol, &it, &lk, &reason, nullptr, 0));
     return Rcpp::List::create(Rcpp::Named("it") = it, Rcpp::Named("lk") = lk, Rcpp::Named("reason") = reason);
 }
+
+// the nrun restarts of a rank (R/factorize.R:181) stepped together: engines made after vbnmf_set_grid(256 %/% B, 256 %/% B),
+// their starts loaded with mlnmf_set_state; one call for all their loops (R/factorize.R:194-213 each)
+// [[Rcpp::export]]
+Rcpp::List mlnmf_run_batch(Rcpp::List engines, int Itmax, double Tol, bool prior = false, double gamma_a = 1.0, double gamma_b = 1.0)
+{
+    const int B = engines.size();
+    std::vector<vbnmf_engine *> es(B);
+    std::vector<int32_t> it(B), reason(B);
+    std::vector<double> lk(B);
+    for (int b = 0; b < B; b++) es[b] = eng(engines[b]);
+    check(vbnmf_batch_ml_run(es.data(), B, prior ? 1 : 0, gamma_a, gamma_b, Itmax, Tol, it.data(), lk.data(), reason.data(), nullptr, 0));
+    return Rcpp::List::create(Rcpp::Named("it") = Rcpp::IntegerVector(it.begin(), it.end()),
+                              Rcpp::Named("lk") = Rcpp::NumericVector(lk.begin(), lk.end()),
+                              Rcpp::Named("reason") = Rcpp::IntegerVector(reason.begin(), reason.end()));
+}
 // [[Rcpp::export]]
 Rcpp::List mlnmf_state(SEXP engine)
 {

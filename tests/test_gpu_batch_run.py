@@ -224,3 +224,78 @@ def test_the_grid_is_a_property_of_the_engines_the_thread_creates_next():
         finally:
             a.close(); b.close()
     M.close()
+
+
+# ---- maximum-likelihood NMF: the restarts of factorize() (reference R/factorize.R:181) stepped together ----------------
+@pytest.mark.parametrize("kind,n,m,r,B,prior", [("clustered", 400, 650, 5, 4, False), ("counts", 150, 230, 3, 7, False),
+                                                 ("noninteger", 120, 260, 7, 3, True), ("counts", 97, 131, 16, 2, False),
+                                                 ("clustered", 300, 500, 10, 16, False), ("counts", 64, 64, 2, 1, False)])
+def test_ml_batch_gives_every_engines_stand_alone_run_bit_for_bit(kind, n, m, r, B, prior):
+    import ccfindr_amd as C
+    X = _matrix(kind, n, m, 5 * r + n)
+    n, m = X.shape
+    M = C.CountMatrix(X)
+    rng = np.random.default_rng(r)
+    starts = [(rng.uniform(0.1, 1.0, size=(n, r)), rng.uniform(0.1, 1.0, size=(r, m))) for _ in range(B)]
+    grid = C.batch_grid(B)
+    for Itmax, Tol in ((60, 1e-4), (1, 0.0), (8, 0.0), (19, 0.0)):          # stops inside the run; Itmax inside / at / beyond a batch of eight
+        kw = dict(Itmax=Itmax, Tol=Tol, prior=prior, gamma_a=1.3, gamma_b=0.7)
+        want = []
+        for w0, h0 in starts:
+            eng = C.VBEngine(M, r, grid=grid)
+            eng.ml_set_state(w0, h0)
+            out = eng.ml_run(history=True, **kw)
+            want.append((out, eng.ml_get_state(), eng.ml_likelihood()))
+            eng.close()
+        engs = [C.VBEngine(M, r, grid=grid) for _ in range(B)]
+        for eng, (w0, h0) in zip(engs, starts):
+            eng.ml_set_state(w0, h0)
+        got = C.run_batch_ml(engs, history=True, **kw)
+        for b in range(B):
+            assert got[b]["it"] == want[b][0]["it"] and got[b]["reason"] == want[b][0]["reason"] and got[b]["lk"] == want[b][0]["lk"]
+            assert np.array_equal(got[b]["history"], want[b][0]["history"])
+            st = engs[b].ml_get_state()
+            assert np.array_equal(st["ew"], want[b][1]["ew"]) and np.array_equal(st["eh"], want[b][1]["eh"])
+            assert engs[b].ml_likelihood() == want[b][2]
+        # the engines go on: a host-stepped ML step from the state the batch left, against the stand-alone engine's
+        ref = C.VBEngine(M, r, grid=grid)
+        ref.ml_set_state(*starts[0])
+        ref.ml_run(**kw)
+        assert engs[0].ml_step(prior, 1.3, 0.7) == ref.ml_step(prior, 1.3, 0.7)
+        ref.close()
+        for eng in engs:
+            eng.close()
+    M.close()
+
+
+def test_factorize_batched_is_the_run_by_run_driver():
+    import ccfindr_amd as C
+    from ccfindr_amd import synth
+    X = synth.drop_empty(synth.simulate_data(300, (80, 120, 100), seed=4, sparse=False))
+    kw = dict(ranks=[2, 3, 4], nrun=7, verbose=0, Tol=1e-6, Itmax=400, seed=5)
+    a = C.factorize(X, batch=3, **kw)                                  # chunks of 3 + 3 + 1
+    M = C.CountMatrix(X)
+    # one restart at a time on the grids a batch of three uses: the same draws, the same runs, the same best
+    rng = np.random.default_rng(5)
+    from ccfindr_amd.factorize import init
+    for irank, rank in enumerate(kw["ranks"]):
+        best, steps = (-np.inf, None), []
+        for irun in range(kw["nrun"]):
+            wh = init(X.shape[0], X.shape[1], rank, rng)
+            eng = C.VBEngine(M, rank, grid=C.batch_grid(3))
+            eng.ml_set_state(wh["ew"], wh["eh"])
+            out = eng.ml_run(Itmax=400, Tol=1e-6)
+            steps.append(out["it"])
+            if irun == 0 or out["lk"] > best[0]:
+                best = (out["lk"], eng.ml_get_state())
+            eng.close()
+        assert a.nsteps[irank] == steps
+        assert a.measure["likelihood"][irank] == best[0]
+        assert np.array_equal(a.basis[irank], best[1]["ew"]) and np.array_equal(a.coeff[irank], best[1]["eh"])
+    M.close()
+    b = C.factorize(X, batch=1, **kw)                                  # default grids: the same factorisation to rounding
+    c = C.factorize(X, **kw)                                           # the default (batched at this size)
+    assert np.allclose(a.measure["likelihood"], b.measure["likelihood"], rtol=1e-9, atol=0.0)
+    assert np.allclose(c.measure["likelihood"], b.measure["likelihood"], rtol=1e-9, atol=0.0)
+    with pytest.raises(ValueError):
+        C.factorize(X, ranks=[2], nrun=1, batch=4, verbose=0, Itmax=5)

@@ -315,6 +315,7 @@ def test_device_driven_ml_loop_equals_host_stepped():
     # the step path works again after a run
     assert eng.ml_step() == host[7]
     eng.close()
-    a = C.factorize(z["X"], ranks=3, nrun=2, verbose=0, Tol=1e-6, Itmax=600, seed=3, device_loop=True)
+    # (batch=1: one restart at a time on the default grids, as the host-stepped loop runs them; a batch sits on smaller grids)
+    a = C.factorize(z["X"], ranks=3, nrun=2, verbose=0, Tol=1e-6, Itmax=600, seed=3, device_loop=True, batch=1)
     b = C.factorize(z["X"], ranks=3, nrun=2, verbose=0, Tol=1e-6, Itmax=600, seed=3, device_loop=False)
     assert a.nsteps == b.nsteps and a.measure == b.measure and np.array_equal(a.basis[0], b.basis[0])
