@@ -413,7 +413,7 @@ def vb_run_rank_batch(iruns, rank, bundle):
 
 
 def batch_eligible(bundle, batch):
-    """How many restarts of a rank vb_factorize steps together: ``batch`` as given (1: never), or -- ``None`` -- up to 16 where
+    """How many restarts of a rank vb_factorize steps together: ``batch`` as given (1: never), or -- ``None`` -- up to 16 (``engine.auto_batch``: 16 / 8 / 4 by matrix size) where
     it pays and is possible: several runs, a matrix small enough that one loop leaves the GPU room (up to 2e7 stored entries:
     x 6 at 3.5e5, x 3.2 at 2e6, x 1.9 at 1.5e7 for eight restarts, profiles/r05_batch_sizes.txt),
     ranks within the batch kernels' range, the device-driven loop, the library's own engines."""
@@ -429,7 +429,8 @@ def batch_eligible(bundle, batch):
             raise ValueError("batch > 1 needs nrun > 1, ranks <= %d, the device-driven loop and the library's own engines" % BATCH_MAX_RANK)
         return 1
     if batch is None:
-        return min(nrun, 16) if bundle["mat"].nnz <= 20_000_000 else 1
+        from .engine import auto_batch
+        return auto_batch(bundle["mat"].nnz, nrun)
     return min(int(batch), nrun, 64)
 
 

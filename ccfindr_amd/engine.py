@@ -495,6 +495,14 @@ def batch_grid(B):
     return (g, g)
 
 
+def auto_batch(nnz, nrun):
+    """How many restarts of a rank the drivers step together when not told: the smaller the matrix, the more of them one launch
+    holds with profit (profiles/r05_batch_sizes.txt, r05_batch_ml.txt: a batch's engines sit on 256 / B workgroups each, too
+    few for a matrix that could use the chip by itself)."""
+    cap = 16 if nnz <= 1_000_000 else 8 if nnz <= 4_000_000 else 4 if nnz <= 20_000_000 else 1
+    return max(1, min(int(nrun), cap))
+
+
 def run_batch(engines, hypers, Itmax=10000, Tol=1e-5, n0=10, dn=1, flags=(True,) * 4, fudge=EPS, history=False):
     """The device-driven loops of several engines of ONE rank on ONE ``CountMatrix`` -- the restarts of a rank, reference
     R/bayesian.R:260-261 -- stepped together (``vbnmf_batch_run``: two launches per step for the whole batch).  Every

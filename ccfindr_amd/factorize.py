@@ -13,7 +13,7 @@ from dataclasses import dataclass, field
 import numpy as np
 
 from . import _native as N
-from .engine import CountMatrix, VBEngine
+from .engine import CountMatrix, VBEngine, auto_batch
 
 BATCH_MAX_RANK = 16          # ranks the batch kernels are built for (csrc/engine.hip: kBatchMaxPaddedRank)
 
@@ -185,7 +185,7 @@ def factorize(mat, ranks=2, nrun=20, randomize=False, nsmpl=1, verbose=2, progre
             nb = 1
             if (engine_factory is None and device_loop and criterion == "likelihood" and verbose < 3 and nrun > 1 and rank <= BATCH_MAX_RANK
                     and (batch is None or int(batch) > 1) and os.environ.get("VBNMF_NO_CONTROL_FOLD", "0") != "1"):
-                nb = min(nrun, 16 if batch is None else int(batch), 64) if (batch is not None or Ms.nnz <= 20_000_000) else 1
+                nb = min(nrun, int(batch), 64) if batch is not None else auto_batch(Ms.nnz, nrun)
             elif batch is not None and int(batch) > 1:
                 raise ValueError("batch > 1 needs nrun > 1, rank <= %d, criterion 'likelihood', the device loop and the library's own engines" % BATCH_MAX_RANK)
             if nb > 1:

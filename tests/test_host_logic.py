@@ -281,6 +281,7 @@ def test_batched_restarts_driver_equals_the_run_by_run_driver(monkeypatch):
     bundle.update(device_loop=True, concurrent=1)
     assert B.batch_eligible(bundle, None) == 5 and B.batch_eligible(bundle, 1) == 1 and B.batch_eligible(bundle, 3) == 3
     assert B.batch_eligible(dict(bundle, nrun=40), None) == 16 and B.batch_eligible(dict(bundle, nrun=1), None) == 1
+    assert E.auto_batch(3e5, 20) == 16 and E.auto_batch(2e6, 20) == 8 and E.auto_batch(1.5e7, 20) == 4 and E.auto_batch(5e7, 20) == 1 and E.auto_batch(3e5, 3) == 3
     assert B.batch_eligible(dict(bundle, ranks=[2, 17]), None) == 1 and B.batch_eligible(dict(bundle, concurrent=4), None) == 1
     with pytest.raises(ValueError):
         B.batch_eligible(dict(bundle, nrun=1), 4)
