@@ -442,7 +442,7 @@ def measure_sweep_traffic(timeout_s=300.0):
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         out = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
         env = {k: v for k, v in os.environ.items() if not k.startswith(prof) and k != "LD_PRELOAD"}
-        env.update(BENCH_NO_SWEEP="1", BENCH_NO_TRAFFIC="1", TMPDIR="/tmp")
+        env.update(BENCH_NO_SWEEP="1", BENCH_NO_TRAFFIC="1", BENCH_NO_SMALL="1", TMPDIR="/tmp")      # (the headline's sweeps only)
         cmd = [tool, "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "pmc", "--", sys.executable,
                os.path.abspath(__file__), "--steps", "24", "--warmup", "2", "--no-cpu", "--no-ml"]
         try:

@@ -1994,6 +1994,52 @@ int launch_update2_batch(vbnmf_engine *e, const Upd2Job *jobs, int B)
     return VBNMF_OK;
 }
 
+// Host side of a batch's device-driven loops (drive_loop's rule over all engines): steps queued in batches of eight, two batches
+// ahead of the device; batch b + 2 is queued when some engine has neither stopped nor fallen short of the last step of batch b.
+// `queue_batch` queues up to eight more steps and counts them in `queued`.  Every engine's result block is polled: [5] = steps done,
+// [6] = reason (raised after [5]), [7] = steps done (raised last).  Returns with e0->poisoned set when the wait timed out.
+template <class QueueBatch>
+int drive_batch_loop(vbnmf_engine **engs, int B, hipStream_t S, int max_it, const int &queued, QueueBatch &&queue_batch, const char *what)
+{
+    vbnmf_engine *e0 = engs[0];
+    if (int rc = queue_batch()) return rc;
+    if (int rc = queue_batch()) return rc;
+    const double limit = wait_timeout_s();
+    for (int bt = 0;; bt++) {
+        const int target = (int)std::min<int64_t>((int64_t)(bt + 1) * 8, max_it);
+        const auto t0 = std::chrono::steady_clock::now();
+        bool all_stopped = false;
+        for (long spins = 1;; spins++) {
+            bool reached = true;
+            all_stopped = true;
+            for (int b = 0; b < B; b++) {
+                volatile double *ho = engs[b]->h_out;
+                const bool stopped = ho[6] != 0.0;
+                all_stopped = all_stopped && stopped;
+                reached = reached && (stopped || (int)ho[7] >= target);
+            }
+            if (reached) break;
+            if ((spins & 0xFFFF) == 0) {
+                const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                if (waited > limit) {
+                    e0->poisoned = true;
+                    return fail(VBNMF_ERR_HIP, "timed out after %.1f s (VBNMF_WAIT_TIMEOUT_S) waiting for step %d of %s (%d queued)", waited, target, what, queued);
+                }
+                hipError_t q = hipStreamQuery(S);
+                if (q != hipSuccess && q != hipErrorNotReady) return fail(VBNMF_ERR_HIP, "%s failed on the device: %s", what, hipGetErrorString(q));
+                if (q == hipSuccess) {                            // idle: everything queued has run; one more look, then a step is lost
+                    bool ok = true;
+                    const int expect = queued - (queued < max_it ? 1 : 0);      // (step t is reported by step t + 1's launch, the last by the closing ones)
+                    for (int b = 0; b < B; b++) { volatile double *ho = engs[b]->h_out; ok = ok && (ho[6] != 0.0 || (int)ho[7] >= std::min(target, expect)); }
+                    if (!ok) return fail(VBNMF_ERR_HIP, "the device went idle before the queued steps of %s finished", what);
+                }
+            }
+        }
+        if (all_stopped || target >= max_it) return VBNMF_OK;
+        if (int rc = queue_batch()) return rc;
+    }
+}
+
 // the fold of step t (1-based) of engine e's run, as queue_vb_step builds it
 ControlFold batch_fold(const vbnmf_engine *e, int t, bool hist)
 {
@@ -2152,42 +2198,7 @@ int vbnmf_batch_run(vbnmf_engine **engs, int32_t count, double *hyper, double fu
         restore(rc);
         return fail(rc, "%s", msg.c_str());
     };
-    if (int rc = queue_batch()) return fail_out(rc);
-    if (int rc = queue_batch()) return fail_out(rc);
-    const double limit = wait_timeout_s();
-    for (int bt = 0;; bt++) {
-        const int target = (int)std::min<int64_t>((int64_t)(bt + 1) * 8, max_it);
-        const auto t0 = std::chrono::steady_clock::now();
-        bool all_stopped = false;
-        for (long spins = 1;; spins++) {
-            bool reached = true;
-            all_stopped = true;
-            for (int b = 0; b < B; b++) {
-                volatile double *ho = engs[b]->h_out;
-                const bool stopped = ho[6] != 0.0;
-                all_stopped = all_stopped && stopped;
-                reached = reached && (stopped || (int)ho[7] >= target);
-            }
-            if (reached) break;
-            if ((spins & 0xFFFF) == 0) {
-                const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-                if (waited > limit) {
-                    e0->poisoned = true;
-                    return fail_out(fail(VBNMF_ERR_HIP, "timed out after %.1f s (VBNMF_WAIT_TIMEOUT_S) waiting for step %d of a batch's device-driven loop (%d queued)", waited, target, queued));
-                }
-                hipError_t q = hipStreamQuery(S);
-                if (q != hipSuccess && q != hipErrorNotReady) return fail_out(fail(VBNMF_ERR_HIP, "the batch's loop failed on the device: %s", hipGetErrorString(q)));
-                if (q == hipSuccess) {                            // idle: everything queued has run; look once more, then it is lost
-                    bool ok = true;
-                    const int expect = queued - (queued < max_it ? 1 : 0);
-                    for (int b = 0; b < B; b++) { volatile double *ho = engs[b]->h_out; ok = ok && (ho[6] != 0.0 || (int)ho[7] >= std::min(target, expect)); }
-                    if (!ok) return fail_out(fail(VBNMF_ERR_HIP, "the device went idle before the queued steps of the batch finished"));
-                }
-            }
-        }
-        if (all_stopped || target >= max_it) break;
-        if (int rc = queue_batch()) return fail_out(rc);
-    }
+    if (int rc = drive_batch_loop(engs, B, S, max_it, queued, queue_batch, "a batch's device-driven loops")) return fail_out(rc);
     {
         hipError_t he = hipStreamSynchronize(S);
         if (he != hipSuccess) return restore(fail(VBNMF_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(he)));
@@ -2398,42 +2409,7 @@ int vbnmf_batch_ml_run(vbnmf_engine **engs, int32_t count, int32_t prior, double
         restore(rc);
         return fail(rc, "%s", msg.c_str());
     };
-    if (int rc = queue_batch()) return fail_out(rc);
-    if (int rc = queue_batch()) return fail_out(rc);
-    const double limit = wait_timeout_s();
-    for (int bt = 0;; bt++) {
-        const int target = (int)std::min<int64_t>((int64_t)(bt + 1) * 8, max_it);
-        const auto t0 = std::chrono::steady_clock::now();
-        bool all_stopped = false;
-        for (long spins = 1;; spins++) {
-            bool reached = true;
-            all_stopped = true;
-            for (int b = 0; b < B; b++) {
-                volatile double *ho = engs[b]->h_out;
-                const bool stopped = ho[6] != 0.0;
-                all_stopped = all_stopped && stopped;
-                reached = reached && (stopped || (int)ho[7] >= target);
-            }
-            if (reached) break;
-            if ((spins & 0xFFFF) == 0) {
-                const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-                if (waited > limit) {
-                    e0->poisoned = true;
-                    return fail_out(fail(VBNMF_ERR_HIP, "timed out after %.1f s (VBNMF_WAIT_TIMEOUT_S) waiting for step %d of a batch's ML loop (%d queued)", waited, target, queued));
-                }
-                hipError_t q = hipStreamQuery(S);
-                if (q != hipSuccess && q != hipErrorNotReady) return fail_out(fail(VBNMF_ERR_HIP, "the batch's loop failed on the device: %s", hipGetErrorString(q)));
-                if (q == hipSuccess) {
-                    bool ok = true;
-                    const int expect = queued - (queued < max_it ? 1 : 0);
-                    for (int b = 0; b < B; b++) { volatile double *ho = engs[b]->h_out; ok = ok && (ho[6] != 0.0 || (int)ho[7] >= std::min(target, expect)); }
-                    if (!ok) return fail_out(fail(VBNMF_ERR_HIP, "the device went idle before the queued steps of the batch finished"));
-                }
-            }
-        }
-        if (all_stopped || target >= max_it) break;
-        if (int rc = queue_batch()) return fail_out(rc);
-    }
+    if (int rc = drive_batch_loop(engs, B, S, max_it, queued, queue_batch, "a batch's ML loops")) return fail_out(rc);
     {
         hipError_t he = hipStreamSynchronize(S);
         if (he != hipSuccess) return restore(fail(VBNMF_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(he)));

@@ -12,7 +12,7 @@ mkdir -p $OUT
 python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 echo "bench done"
 export TMPDIR=/tmp
-export BENCH_NO_TRAFFIC=1 BENCH_NO_SWEEP=1        # (no nested profiler runs; the profiled passes hold the headline's kernels only: the C4 rank sweep would mix 19 ranks' k_sweep into the means)
+export BENCH_NO_TRAFFIC=1 BENCH_NO_SWEEP=1 BENCH_NO_SMALL=1        # (no nested profiler runs; the profiled passes hold the headline's kernels only: the C4 rank sweep would mix 19 ranks' k_sweep into the means)
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -o stats -- python3 $REPO/bench.py --steps 200 --warmup 10 --no-cpu > $OUT/${TAG}_stats_bench.json 2> $OUT/${TAG}_stats.err
 echo "stats done"
