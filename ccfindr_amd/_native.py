@@ -99,6 +99,7 @@ SIGNATURES = {
     "vbnmf_engine_run": (ctypes.c_int, [_VP, c_double_p, _D, _I32, _D, _I32, _I32, c_int32_p, c_int32_p, c_double_p,
                                         c_double_p, c_int32_p, c_double_p, _I64]),
     "vbnmf_set_engine_grid": (ctypes.c_int, [_I32, _I32]),
+    "vbnmf_set_engine_padding": (ctypes.c_int, [_I32]),
     "vbnmf_batch_run": (ctypes.c_int, [_VPP, _I32, c_double_p, _D, _I32, _D, _I32, _I32, c_int32_p, c_int32_p, c_double_p,
                                        c_double_p, c_int32_p, c_double_p, _I64]),
     "vbnmf_batch_ml_run": (ctypes.c_int, [_VPP, _I32, _I32, _D, _D, _I32, _D, c_int32_p, c_double_p, c_int32_p, c_double_p, _I64]),

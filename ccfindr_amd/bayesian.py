@@ -265,7 +265,7 @@ def _make_engine(bundle, rank, slot=None):
     factory = bundle.get("engine_factory")
     eng = (factory(bundle["mat"], rank) if factory is not None else
            VBEngine(bundle["mat"], rank, device=bundle.get("device", 0), geometry_rank=geometry_rank_for(rank, bundle.get("classes")),
-                    grid=bundle.get("grid")))
+                    grid=bundle.get("grid"), pad_rank=bundle.get("pad_rank")))
     if cache is not None:
         cache[key] = eng
     return eng
@@ -365,19 +365,26 @@ def _unit_record(rank, bundle, wh, in_place, lk0, hyper, it):
 
 
 def vb_run_rank_batch(iruns, rank, bundle):
-    """The restarts ``iruns`` of ONE rank (reference R/bayesian.R:260-261: ``lapply(seq_len(nrun), vb_iterate)``; here rank by
-    rank), stepped together by ``engine.run_batch``: on a small matrix one loop cannot fill the GPU and concurrent streams do
-    not overlap (profiles/r05_small_concurrent.txt), so the independent loops share their launches.  Every unit draws its
-    start from its own (run, rank) stream and follows its own control block: the records are vb_run_rank's, bit for bit."""
+    """The restarts ``iruns`` of ONE rank, stepped together: ``vb_run_units_batch`` on the units (irun, rank)."""
+    return vb_run_units_batch([(irun, rank) for irun in iruns], bundle)
+
+
+def vb_run_units_batch(units, bundle):
+    """The (run, rank) units ``units`` -- the restarts of a rank (reference R/bayesian.R:260-261: ``lapply(seq_len(nrun),
+    vb_iterate)``), and, where the engines are made one row width wide (``bundle["pad_rank"]``), several ranks of the rank loop
+    (:316) as well -- stepped together by ``engine.run_batch``: on a small matrix one loop cannot fill the GPU and concurrent
+    streams do not overlap (profiles/r05_small_concurrent.txt), so the independent loops share their launches.  Every unit draws
+    its start from its own (run, rank) stream and follows its own control block: the records are vb_run_rank's on engines of the
+    same grid and width, bit for bit."""
     from .engine import run_batch
     X = bundle["mat"]
     nrow, ncol = X.shape
-    if rank > min(nrow, ncol):
-        raise ValueError("Rank exceeded min(nrow,ncol)")                         # :319-320
     ga, gb = np.atleast_1d(bundle["gamma_a"]), np.atleast_1d(bundle["gamma_b"])
     raw = bundle.get("raw")
     engines, hypers = [], []
-    for slot, irun in enumerate(iruns):
+    for slot, (irun, rank) in enumerate(units):
+        if rank > min(nrow, ncol):
+            raise ValueError("Rank exceeded min(nrow,ncol)")                     # :319-320
         hyper = {"aw": float(ga[0]), "ah": float(ga[-1]), "bw": float(gb[0]), "bh": float(gb[-1])}   # :321-326
         rng = _bundle_rng(bundle, irun, rank)
         eng = _make_engine(bundle, rank, slot)
@@ -394,7 +401,7 @@ def vb_run_rank_batch(iruns, rank, bundle):
     if any(o["reason"] == 3 for o in outs):
         raise RuntimeError("Hyper-parameter update failed to converge")          # reference R/bayesian.R:43
     recs = []
-    for irun, eng, out in zip(iruns, engines, outs):
+    for (irun, rank), eng, out in zip(units, engines, outs):
         slots = bundle["state_out"](irun, rank) if bundle.get("state_out") is not None else None
         if slots is not None and getattr(eng, "supports_state_out", False):
             wh = eng.get_state(("ew", "eh", "dw", "dh"), out=slots)
@@ -412,46 +419,67 @@ def vb_run_rank_batch(iruns, rank, bundle):
     return recs
 
 
-def batch_eligible(bundle, batch):
-    """How many restarts of a rank vb_factorize steps together: ``batch`` as given (1: never), or -- ``None`` -- up to 16 (``engine.auto_batch``: 16 / 8 / 4 by matrix size) where
-    it pays and is possible: several runs, a matrix small enough that one loop leaves the GPU room (up to 2e7 stored entries:
-    x 6 at 3.5e5, x 3.2 at 2e6, x 1.9 at 1.5e7 for eight restarts, profiles/r05_batch_sizes.txt),
-    ranks within the batch kernels' range, the device-driven loop, the library's own engines."""
-    nrun = bundle["nrun"]
+def batch_across_ranks(bundle, across):
+    """Whether a batch also takes several RANKS of the rank loop (reference R/bayesian.R:316): the engines of all ranks are then
+    made one row width wide (the widest rank's), which costs the narrow ranks idle columns in the sweep -- nothing on a matrix
+    whose step is latency bound anyway.  ``across`` as given, or -- ``None`` -- up to 2e6 stored entries."""
+    if len(bundle["ranks"]) < 2 or across is False:
+        return False
+    return True if across else bundle["mat"].nnz <= 2_000_000
+
+
+def batch_eligible(bundle, batch, across=None):
+    """How many (run, rank) units vb_factorize steps together: ``batch`` as given (1: never), or -- ``None`` -- up to 16
+    (``engine.auto_batch``: 16 / 8 / 4 by matrix size) where it pays and is possible: several units -- the ``nrun`` restarts of a
+    rank, times the ranks where a batch spans ranks (``batch_across_ranks``) --, a matrix small enough that one loop leaves the
+    GPU room (up to 2e7 stored entries: x 6 at 3.5e5, x 3.2 at 2e6, x 1.9 at 1.5e7 for eight restarts,
+    profiles/r05_batch_sizes.txt), ranks within the batch kernels' range, the device-driven loop, the library's own engines."""
     if batch is not None and int(batch) <= 1:
         return 1
-    ok = (nrun > 1 and bundle.get("engine_factory") is None and bundle.get("device_loop", True) and bundle["verbose"] < 3 and
+    units = bundle["nrun"] * (len(bundle["ranks"]) if batch_across_ranks(bundle, across) else 1)
+    ok = (units > 1 and bundle.get("engine_factory") is None and bundle.get("device_loop", True) and bundle["verbose"] < 3 and
           bundle.get("concurrent", 1) == 1 and not getattr(bundle["mat"], "is_shell", False) and
           max(bundle["ranks"], default=0) <= BATCH_MAX_RANK and os.environ.get("VBNMF_NO_UPDATE_PAIR", "0") != "1" and
           os.environ.get("VBNMF_NO_CONTROL_FOLD", "0") != "1")
     if not ok:
         if batch is not None:
-            raise ValueError("batch > 1 needs nrun > 1, ranks <= %d, the device-driven loop and the library's own engines" % BATCH_MAX_RANK)
+            raise ValueError("batch > 1 needs several (run, rank) units, ranks <= %d, the device-driven loop and the library's own engines" % BATCH_MAX_RANK)
         return 1
     if batch is None:
         from .engine import auto_batch
-        return auto_batch(bundle["mat"].nnz, nrun)
-    return min(int(batch), nrun, 64)
+        return auto_batch(bundle["mat"].nnz, units)
+    return min(int(batch), units, 64)
 
 
 def vb_iterate_batched(bundle, batch):
-    """All runs, rank by rank, the runs still scanning stepped ``batch`` at a time (vb_run_rank_batch); a run's scan ends at a
-    rank with a constant basis column under ``unif_stop`` exactly as in vb_iterate (reference R/bayesian.R:373-377)."""
+    """All runs, the (run, rank) units stepped ``batch`` at a time (vb_run_units_batch).  With ``bundle["pad_rank"]`` set the
+    engines of all ranks are one row width wide and a batch takes the runs still scanning times as many CONSECUTIVE ranks as fit
+    (the higher ranks of a group are run ahead of the scan: a run whose scan ends inside the group -- a constant basis column
+    under ``unif_stop``, reference R/bayesian.R:373-377 -- has their results dropped, exactly as if they had not been run);
+    without it, rank by rank.  The records and the bookkeeping are vb_iterate's."""
     ranks = [int(r) for r in bundle["ranks"]]
     alive = list(range(1, bundle["nrun"] + 1))
     records = {irun: {} for irun in alive}
-    for rank in ranks:
-        if not alive:
-            break
-        for c0 in range(0, len(alive), batch):
-            chunk = alive[c0:c0 + batch]
-            for irun, rec in zip(chunk, vb_run_rank_batch(chunk, rank, bundle)):
-                records[irun][rank] = rec
-        if bundle["unif_stop"]:
-            alive = [irun for irun in alive if not records[irun][rank]["unif"]]
-        cache = bundle.get("engines")                                            # this rank's engines are done with
-        for key in [k for k in (cache or {}) if isinstance(k, tuple) and k[0] == "slot" and k[2] == rank]:
+    across = bundle.get("pad_rank") is not None
+    k = 0
+    while k < len(ranks) and alive:
+        width = max(1, batch // len(alive)) if across else 1                     # consecutive ranks taken together
+        group = ranks[k:k + width]
+        units = [(irun, rank) for rank in group for irun in alive]
+        got = {}
+        for c0 in range(0, len(units), batch):
+            chunk = units[c0:c0 + batch]
+            for unit, rec in zip(chunk, vb_run_units_batch(chunk, bundle)):
+                got[unit] = rec
+        for rank in group:                                                       # the scan, rank by rank (:316, :373-377)
+            for irun in alive:
+                records[irun][rank] = got[(irun, rank)]
+            if bundle["unif_stop"]:
+                alive = [irun for irun in alive if not records[irun][rank]["unif"]]
+        cache = bundle.get("engines")                                            # these ranks' engines are done with
+        for key in [q for q in (cache or {}) if isinstance(q, tuple) and q[0] == "slot" and q[2] in group]:
             cache.pop(key).close()
+        k += len(group)
     return [assemble_run(records[irun], ranks, bundle["unif_stop"]) for irun in range(1, bundle["nrun"] + 1)]
 
 
@@ -559,7 +587,7 @@ def vb_factorize(mat, ranks=2, nrun=1, verbose=2, progress_bar=True, initializer
                  hyper_update=(True, True, True, True), gamma_a=1, gamma_b=1, Tol=1e-5,
                  hyper_update_n0=10, hyper_update_dn=1, connectivity=False, fudge=None, ncores=1,
                  useC=True, unif_stop=True, seed=None, device=0, engine_factory=None, device_loop=True, concurrent=1,
-                 device_init=False, geometry_classes=1, batch=None, grid=None):
+                 device_init=False, geometry_classes=1, batch=None, grid=None, across_ranks=None, pad_rank=None):
     """Bayesian NMF of a count matrix on the MI355X engine; reference R/bayesian.R:229-301.
 
     ``mat`` is the genes x cells count matrix (dense, scipy sparse, or ``CountMatrix``).
@@ -577,6 +605,12 @@ def vb_factorize(mat, ranks=2, nrun=1, verbose=2, progress_bar=True, initializer
     ``device_init`` draws the ``random`` initial state on the GPU (``vbnmf_engine_random_state``: Philox counters +
     Marsaglia-Tsang, one key per (seed, run, rank)) instead of with numpy on the host; off by default so that runs
     with an injected engine and runs on the HIP engine start from the same arrays.
+    ``batch``: how many (run, rank) units are stepped by ONE launch (``engine.run_batch`` / ``vbnmf_batch_run``; 1: one loop at a
+    time; None: ``batch_eligible`` -- up to 16 on small matrices): on the matrices the reference ships one loop cannot fill the
+    GPU.  ``across_ranks`` (None: up to 2e6 stored entries): a batch also spans consecutive ranks of the rank loop, every engine
+    made as wide as the widest rank's (``pad_rank``), so that a rank sweep with ``nrun`` = 1 batches as well.  ``grid``, ``pad_rank``:
+    the launch grids and the row width of every engine (``VBEngine``); they fix the order of the block-wise sums, so runs on
+    different grids or widths -- and hence ``batch=1`` against the default -- agree to rounding, not bit for bit.
     ``geometry_classes``: see ``plan_geometry`` (several ranks share the tiled layouts of the largest one; 0 = off).
     With shared layouts a rank's numbers depend, in the last bits, on WHICH ranks are in the sweep: the geometry fixes the
     order in which a step's partial sums are added (every result stays inside the 1e-12 / 1e-10 tolerances of one step,
@@ -592,6 +626,7 @@ def vb_factorize(mat, ranks=2, nrun=1, verbose=2, progress_bar=True, initializer
     bundle["device_init"] = bool(device_init)
     bundle["concurrent"] = max(1, int(concurrent))
     bundle["grid"] = grid                               # (sweep workgroups, update blocks) of every engine; None: one per CU
+    bundle["pad_rank"] = pad_rank                       # row width of every engine (a padded rank >= the widest rank's); None: each rank's own
     bundle["engines"] = {} if (nrun > 1 or bundle["concurrent"] > 1) else None   # restarts of a rank reuse its engine
     plan_geometry(bundle, geometry_classes)
     try:
@@ -614,11 +649,13 @@ def vb_factorize(mat, ranks=2, nrun=1, verbose=2, progress_bar=True, initializer
             records = dict(zip(units, recs))
             vb = [assemble_run({r: records[(irun, int(r))] for r in bundle["ranks"]}, [int(r) for r in bundle["ranks"]], unif_stop)
                   for irun in range(1, nrun + 1)]
-        elif batch_eligible(bundle, batch) > 1:
-            from .engine import batch_grid
-            nb = batch_eligible(bundle, batch)
+        elif batch_eligible(bundle, batch, across_ranks) > 1:
+            from .engine import batch_grid, padded_rank
+            nb = batch_eligible(bundle, batch, across_ranks)
             bundle["grid"] = batch_grid(nb) if grid is None else grid          # B engines x 256 / B workgroups: one launch fills the chip
-            vb = vb_iterate_batched(bundle, nb)                                  # :260-261, the runs of a rank in one launch
+            if batch_across_ranks(bundle, across_ranks):                         # every rank's engine as wide as the widest rank's:
+                bundle["pad_rank"] = padded_rank(max(bundle["ranks"]))          # one batch may then span ranks
+            vb = vb_iterate_batched(bundle, nb)                                  # :260-261 (and :316): many loops, one launch
         else:
             vb = [vb_iterate(irun, bundle) for irun in range(1, nrun + 1)]       # :260-261
     finally:

@@ -189,6 +189,8 @@ int dev_upload(T **p, const std::vector<T, A> &v)
 namespace vbnmf {
 // vbnmf_set_engine_grid: the grids of the engines THIS host thread creates next (0: the defaults)
 static thread_local int tl_grid_nwg = 0, tl_grid_ub = 0;
+// vbnmf_set_engine_padding: the padded rank (row width) of the engines THIS host thread creates next (0: the rank's own)
+static thread_local int tl_pad_R = 0;
 
 int sweep_workgroups(int device, bool partitioned, int &n_wg)
 {
@@ -1028,6 +1030,7 @@ int vbnmf_engine_create_geom(const vbnmf_matrix *X, int64_t cb, int64_t ce, int6
     e->device = device;
     e->n = X->M.n; e->m = ce - cb; e->m_global = m_global; e->col_begin = cb;
     e->r = r; e->R = padded_rank(r);
+    if (tl_pad_R > e->R) e->R = tl_pad_R;                    // (engines of several ranks meant for ONE batch: vbnmf_set_engine_padding)
     e->NT = sweep_threads(e->R);
     {
         // Blocks of the update kernels.  Fewer than one per CU on small matrices (one pass of the longer factor per block)
@@ -1072,7 +1075,7 @@ int vbnmf_engine_create_geom(const vbnmf_matrix *X, int64_t cb, int64_t ce, int6
             const int64_t nmaj = side == 0 ? e->n : e->m, nmin = side == 0 ? e->m : e->n;
             // The geometry is that of the matrix's rank CLASS (vbnmf_matrix_plan_ranks; without a plan the class is this
             // rank's own): the ranks of a sweep share one pair of layouts, cut for the widest rows among them.
-            const int Rc = geometry_rank ? padded_rank(geometry_rank) : std::max(e->R, plan_class(X, e->R));
+            const int Rc = std::max(e->R, geometry_rank ? padded_rank(geometry_rank) : plan_class(X, e->R));
             const int64_t nnz_part = (cb == 0 && ce == X->M.m) ? X->M.nnz : X->M.colptr[ce] - X->M.colptr[cb];
             LayoutParams lp = default_layout_params(nmaj, nmin, Rc, e->n_wg, nnz_part);
             std::shared_ptr<const Layout> &shared = shared2[side];
@@ -2068,6 +2071,19 @@ int vbnmf_set_engine_grid(int32_t n_wg, int32_t update_blocks)
     return VBNMF_OK;
 }
 
+// Row width of the engines the CALLING host thread creates from now on: their factors are stored `padded_rank` columns wide
+// (a padded rank the kernels are built for, >= the engine's own; 0: back to the rank's own width), the columns beyond the rank
+// held at zero as the padding always is.  Engines of DIFFERENT ranks made this way share kernels, layouts and update table, i.e.
+// a batch: a whole rank sweep of a small matrix steps in one launch.  The width fixes the update's thread mapping, hence the
+// order of its block-wise sums: a padded engine agrees with the unpadded one to rounding, not bit for bit.
+int vbnmf_set_engine_padding(int32_t padded)
+{
+    if (padded != 0 && (padded < 2 || padded > VBNMF_MAX_RANK || padded_rank(padded) != padded))
+        return fail(VBNMF_ERR_BAD_ARG, "%d is not a padded rank (even up to 32, a multiple of 8 up to 64, of 16 up to %d)", padded, VBNMF_MAX_RANK);
+    tl_pad_R = padded;
+    return VBNMF_OK;
+}
+
 // The device-driven loops of `count` engines of ONE rank on ONE matrix (the restarts of a rank: same layouts, grids and update
 // table; each engine its own state), stepped TOGETHER: two launches per step for the whole batch, every engine's blocks
 // following its own control block (its own hyper-parameters, evidence, stop).  Results per engine are those of
@@ -2091,10 +2107,10 @@ int vbnmf_batch_run(vbnmf_engine **engs, int32_t count, double *hyper, double fu
         if (int rc = use_device(e)) return rc;
         if (e->partitioned || e->comm || !e->pair || !e->fold || e->R > kBatchMaxPaddedRank)
             return fail(VBNMF_ERR_STATE, "a batch takes unpartitioned engines of the one-launch update form and padded rank <= %d", kBatchMaxPaddedRank);
-        if (e->device != e0->device || e->n != e0->n || e->m != e0->m || e->r != e0->r || e->R != e0->R || e->n_wg != e0->n_wg || e->ub != e0->ub ||
+        if (e->device != e0->device || e->n != e0->n || e->m != e0->m || e->R != e0->R || e->n_wg != e0->n_wg || e->ub != e0->ub ||
             e->NT != e0->NT || e->wide != e0->wide || e->lds_bytes != e0->lds_bytes || e->upd_stride4 != e0->upd_stride4 || e->upd_V != e0->upd_V ||
             e->upd_ids_off != e0->upd_ids_off || e->A.n_slices != e0->A.n_slices || e->B.n_slices != e0->B.n_slices)
-            return fail(VBNMF_ERR_STATE, "the engines of a batch must be of one rank on one matrix (same layouts, grids and update table)");
+            return fail(VBNMF_ERR_STATE, "the engines of a batch must be of one row width on one matrix (same padded rank, layouts, grids and update table)");
         if (!e->has_state || !e->stats_ready) return fail(VBNMF_ERR_STATE, "batch run before set_state");
         if (e->step_pending) return fail(VBNMF_ERR_STATE, "batch run between step_local and step_finish");
         if (history) { if (int rc = ensure_history(e, (size_t)max_it * 9)) return rc; }
@@ -2297,9 +2313,9 @@ int vbnmf_batch_ml_run(vbnmf_engine **engs, int32_t count, int32_t prior, double
         if (int rc = use_device(e)) return rc;
         if (e->partitioned || e->comm || !e->fold || !e->bpH_alt || e->R > kBatchMaxPaddedRank)
             return fail(VBNMF_ERR_STATE, "a batch takes unpartitioned engines with the control step folded in and padded rank <= %d", kBatchMaxPaddedRank);
-        if (e->device != e0->device || e->n != e0->n || e->m != e0->m || e->r != e0->r || e->R != e0->R || e->n_wg != e0->n_wg || e->ub != e0->ub ||
+        if (e->device != e0->device || e->n != e0->n || e->m != e0->m || e->R != e0->R || e->n_wg != e0->n_wg || e->ub != e0->ub ||
             e->NT != e0->NT || e->wide != e0->wide || e->lds_bytes != e0->lds_bytes || e->A.n_slices != e0->A.n_slices || e->B.n_slices != e0->B.n_slices)
-            return fail(VBNMF_ERR_STATE, "the engines of a batch must be of one rank on one matrix (same layouts and grids)");
+            return fail(VBNMF_ERR_STATE, "the engines of a batch must be of one row width on one matrix (same padded rank, layouts and grids)");
         if (!e->ml_ready) return fail(VBNMF_ERR_STATE, "batch ML run before ml_set_state");
         if (history) { if (int rc = ensure_history(e, (size_t)max_it)) return rc; }
     }

@@ -255,25 +255,32 @@ class _CudaBuffer:
 class VBEngine:
     """Device-resident state of one factorisation (one rank, one column block of X)."""
 
-    def __init__(self, X: CountMatrix, rank: int, device: int = 0, cols=None, m_global=None, geometry_rank: int = 0, grid=None):
+    def __init__(self, X: CountMatrix, rank: int, device: int = 0, cols=None, m_global=None, geometry_rank: int = 0, grid=None,
+                 pad_rank=None):
         """``geometry_rank`` (>= rank): the rank whose LDS row size the tiled layouts are cut for -- the ranks of a sweep
         share one pair of layouts (``rank_classes``); 0: the matrix's plan (``CountMatrix.plan_ranks``) or the rank's own.
         ``grid`` = (sweep workgroups, update blocks): an engine meant for a batch of B (``run_batch``) wants 256 / B of each
-        (``vbnmf_set_engine_grid``); None: one per CU."""
+        (``vbnmf_set_engine_grid``); None: one per CU.  ``pad_rank``: the engine's factors are stored that many columns wide (a
+        padded rank >= this rank's own, ``vbnmf_set_engine_padding``): engines of different ranks made with one ``pad_rank`` may
+        share a batch; None: the rank's own width."""
         L = N.load()
         self._lib = L
         self._h = ctypes.c_void_p()
         self.X = X
         cb, ce = (0, X.shape[1]) if cols is None else cols
         mg = X.shape[1] if m_global is None else m_global
-        if grid is not None:
-            N.check(L.vbnmf_set_engine_grid(int(grid[0]), int(grid[1])))
         try:
+            if grid is not None:
+                N.check(L.vbnmf_set_engine_grid(int(grid[0]), int(grid[1])))
+            if pad_rank:
+                N.check(L.vbnmf_set_engine_padding(int(pad_rank)))
             N.check(L.vbnmf_engine_create_geom(X._h, int(cb), int(ce), int(mg), int(rank), int(geometry_rank), int(device),
                                                ctypes.byref(self._h)))
         finally:
             if grid is not None:
                 L.vbnmf_set_engine_grid(0, 0)
+            if pad_rank:
+                L.vbnmf_set_engine_padding(0)
         n, m, r = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int32()
         N.check(L.vbnmf_engine_dims(self._h, ctypes.byref(n), ctypes.byref(m), ctypes.byref(r)))
         self.n, self.m, self.rank = n.value, m.value, r.value
@@ -487,6 +494,11 @@ class VBEngine:
             self.close()
         except Exception:
             pass
+
+
+def padded_rank(rank):
+    """The row width the kernels store a factor of this rank in (``vbnmf_padded_rank``)."""
+    return int(N.load().vbnmf_padded_rank(int(rank)))
 
 
 def batch_grid(B):

@@ -244,12 +244,19 @@ int vbnmf_engine_run(vbnmf_engine *e, double *hyper, double fudge, int32_t max_i
  * (hyper-parameters, evidence, stop -- an engine that has stopped idles through the others' remaining steps).  Per engine the
  * results are those of vbnmf_engine_run on it alone, bit for bit.  hyper: [count][4] in / out; it_out, lk0_out, lkh_out,
  * reason_out: [count] (any may be NULL); history (or NULL): [count][history_rows][9], history_rows >= max_it.
- * Engines: unpartitioned, no communicator, rank <= 16, count <= 64; the launches go on the first engine's stream. */
+ * Engines: unpartitioned, no communicator, padded rank <= 16, count <= 64, of ONE row width (one rank, or several ranks made
+ * under vbnmf_set_engine_padding); the launches go on the first engine's stream. */
 /* Grids of the engines the CALLING host thread creates from now on (0, 0: back to the defaults, one workgroup / block per
  * CU): engines meant for a batch of B want 256 / B of each -- B engines step in one launch of B x grid workgroups.  The
  * grid is part of the order of the block-wise sums: engines of different grids agree to rounding, not bit for bit.  (No
  * reference counterpart: launch geometry.) */
 int vbnmf_set_engine_grid(int32_t n_wg, int32_t update_blocks);
+/* Row width of the engines the CALLING host thread creates from now on: `padded_rank` columns (a padded rank >= the engine's
+ * own: even up to 32, a multiple of 8 up to 64, of 16 beyond; 0: back to the rank's own), the columns beyond the rank held at
+ * zero.  Engines of DIFFERENT ranks made this way share kernels, layouts and update table and may form one batch: the rank
+ * loop of vb_iterate (R/bayesian.R:316) as well as the restarts step in one launch on a small matrix.  A padded engine agrees
+ * with the unpadded one to rounding (the width fixes the update's thread mapping), not bit for bit. */
+int vbnmf_set_engine_padding(int32_t padded_rank);
 int vbnmf_batch_run(vbnmf_engine **engines, int32_t count, double *hyper, double fudge, int32_t max_it, double tol,
                     int32_t n0, int32_t dn, const int32_t *flags, int32_t *it_out, double *lk0_out, double *lkh_out,
                     int32_t *reason_out, double *history, int64_t history_rows);

@@ -152,6 +152,11 @@ Rcpp::List vbnmf_run(SEXP engine, Rcpp::NumericVector hyper, double fudge, int I
 // [[Rcpp::export]]
 void vbnmf_set_grid(int n_wg = 0, int update_blocks = 0) { check(vbnmf_set_engine_grid(n_wg, update_blocks)); }
 
+// engines of SEVERAL ranks in one batch (the rank loop, R/bayesian.R:316): made after vbnmf_set_padding(vbnmf_padded(max(ranks)))
+// they are all as wide as the widest rank's; vbnmf_set_padding(0) afterwards
+// [[Rcpp::export]]
+void vbnmf_set_padding(int padded_rank = 0) { check(vbnmf_set_engine_padding(padded_rank)); }
+
 // [[Rcpp::export]]
 Rcpp::List vbnmf_run_batch(Rcpp::List engines, Rcpp::NumericMatrix hyper, double fudge, int Itmax, double Tol, int n0, int dn,
                            Rcpp::LogicalVector hyper_update)

@@ -148,14 +148,14 @@ def test_what_a_batch_refuses():
     X = _matrix("counts", 120, 160, 2)
     n, m = X.shape
     M = C.CountMatrix(X)
-    a, b = C.VBEngine(M, 3), C.VBEngine(M, 4)
-    wh3, wh4 = synth.random_state(n, m, 3, HY, seed=1), synth.random_state(n, m, 4, HY, seed=1)
+    a, b = C.VBEngine(M, 3), C.VBEngine(M, 5)
+    wh3, wh4 = synth.random_state(n, m, 3, HY, seed=1), synth.random_state(n, m, 5, HY, seed=1)
     a.set_state(wh3["lw"], wh3["lh"], wh3["eh"])
     blank = C.VBEngine(M, 3)
     with pytest.raises(C.VBNMFError):                          # an engine without a state
         C.run_batch([a, blank], [HY, HY], Itmax=3)
     b.set_state(wh4["lw"], wh4["lh"], wh4["eh"])
-    with pytest.raises(C.VBNMFError):                          # two ranks (3 and 4 pad to the same width, the ranks differ)
+    with pytest.raises(C.VBNMFError):                          # two row widths (ranks 3 and 5: four and six columns)
         C.run_batch([a, b], [HY, HY], Itmax=3)
     with pytest.raises(C.VBNMFError):                          # the same engine twice
         C.run_batch([a, a], [HY, HY], Itmax=3)
@@ -181,10 +181,11 @@ def test_vb_factorize_batched_is_the_sequential_driver(unif_stop):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         a = C.vb_factorize(M, batch=1, grid=C.batch_grid(3), **kw)       # one unit at a time, on the grids a batch of 3 uses
-        b = C.vb_factorize(M, batch=3, **kw)                              # (chunks of 3 + 2)
-        c = C.vb_factorize(M, **kw)                                       # the default: batched at this size (5 at a time)
-        d = C.vb_factorize(M, batch=1, grid=C.batch_grid(5), **kw)
-        e = C.vb_factorize(M, batch=1, **kw)                              # the default grids (one per CU)
+        b = C.vb_factorize(M, batch=3, across_ranks=False, **kw)          # the restarts of a rank, chunks of 3 + 2
+        c = C.vb_factorize(M, **kw)                                       # the default at this size: 16 units at a time, across ranks
+        nb = C.engine.auto_batch(M.nnz, 5 * 5)
+        d = C.vb_factorize(M, batch=1, grid=C.batch_grid(nb), pad_rank=C.engine.padded_rank(6), **kw)
+        e = C.vb_factorize(M, batch=1, **kw)                              # the default grids (one per CU), every rank its own width
     for one, other in ((a, b), (d, c)):
         assert one.ranks == other.ranks and one.measure == other.measure and one.nsteps == other.nsteps
         for x, y in zip(one.basis + one.coeff + one.dbasis + one.dcoeff, other.basis + other.coeff + other.dbasis + other.dcoeff):
@@ -299,3 +300,73 @@ def test_factorize_batched_is_the_run_by_run_driver():
     assert np.allclose(c.measure["likelihood"], b.measure["likelihood"], rtol=1e-9, atol=0.0)
     with pytest.raises(ValueError):
         C.factorize(X, ranks=[2], nrun=1, batch=4, verbose=0, Itmax=5)
+
+
+# ---- engines of several ranks in one batch: one row width (vbnmf_set_engine_padding) -----------------------------------------
+def test_a_batch_spans_ranks_when_the_engines_are_one_width():
+    """Engines of ranks 2..8 made eight columns wide share kernels, layouts and update table: one batch; per engine the stand-alone
+    run on an engine of the same width, bit for bit; against the engine of the rank's own width, the same step to rounding."""
+    import ccfindr_amd as C
+    from ccfindr_amd import synth
+    X = _matrix("clustered", 400, 650, 17)
+    n, m = X.shape
+    M = C.CountMatrix(X)
+    ranks = [2, 3, 4, 5, 7, 8]
+    pad = C.engine.padded_rank(max(ranks))
+    assert pad == 8
+    grid = C.batch_grid(len(ranks))
+    whs = [synth.random_state(n, m, r, HY, seed=r) for r in ranks]
+    kw = dict(Itmax=90, Tol=3e-4, n0=4, dn=1)
+    want = []
+    for r, wh in zip(ranks, whs):
+        eng = C.VBEngine(M, r, grid=grid, pad_rank=pad, geometry_rank=max(ranks))
+        eng.set_state(wh["lw"], wh["lh"], wh["eh"])
+        want.append((eng.run(HY, history=True, **kw), eng.get_state()))
+        eng.close()
+    engs = [C.VBEngine(M, r, grid=grid, pad_rank=pad, geometry_rank=max(ranks)) for r in ranks]
+    for eng, wh in zip(engs, whs):
+        eng.set_state(wh["lw"], wh["lh"], wh["eh"])
+    got = C.run_batch(engs, [HY] * len(ranks), history=True, **kw)
+    for b, r in enumerate(ranks):
+        _same(got[b], want[b][0])
+        st = engs[b].get_state()
+        assert st["lw"].shape == (n, r) and st["lh"].shape == (r, m)
+        for k in st:
+            assert np.array_equal(st[k], want[b][1][k]), (r, k)
+    for eng in engs:
+        eng.close()
+    # a padded engine against the rank's own width: three steps agree to rounding
+    for r, wh in zip(ranks[:3], whs[:3]):
+        lks = []
+        for pr in (pad, None):
+            eng = C.VBEngine(M, r, pad_rank=pr)
+            eng.set_state(wh["lw"], wh["lh"], wh["eh"])
+            lks.append([eng.step(HY)[0] for _ in range(3)])
+            eng.close()
+        assert np.allclose(lks[0], lks[1], rtol=1e-12, atol=0.0)
+    with pytest.raises(C.VBNMFError):
+        C.VBEngine(M, 3, pad_rank=7)                           # not a padded rank
+    M.close()
+
+
+@pytest.mark.parametrize("nrun,unif_stop", [(1, True), (3, False)])
+def test_vb_factorize_batched_across_ranks_is_the_unit_by_unit_driver(nrun, unif_stop):
+    """nrun = 1 is the reference's default: the units of a small matrix's rank sweep are then its ranks.  The batched driver
+    (units grouped over consecutive ranks) against one unit at a time on engines of the same grid and width."""
+    import warnings
+    import ccfindr_amd as C
+    from ccfindr_amd import synth
+    X = synth.drop_empty(synth.simulate_data(400, (100, 150, 250), seed=9, sparse=True))
+    M = C.CountMatrix(X)
+    kw = dict(ranks=range(2, 9), nrun=nrun, verbose=0, Tol=1e-5, seed=11, Itmax=300, unif_stop=unif_stop)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a = C.vb_factorize(M, **kw)                                                       # default: batched across ranks at this size
+        nb = C.engine.auto_batch(M.nnz, nrun * 7)
+        b = C.vb_factorize(M, batch=1, grid=C.batch_grid(nb), pad_rank=C.engine.padded_rank(8), **kw)
+        c = C.vb_factorize(M, batch=1, **kw)                                              # the ranks' own widths, default grids
+    assert a.ranks == b.ranks and a.measure == b.measure and a.nsteps == b.nsteps
+    for x, y in zip(a.basis + a.coeff, b.basis + b.coeff):
+        assert np.array_equal(x, y)
+    assert a.ranks == c.ranks and np.allclose(a.measure["lml"], c.measure["lml"], rtol=1e-7, atol=0.0)
+    M.close()

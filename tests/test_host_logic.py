@@ -259,30 +259,36 @@ def test_batched_restarts_driver_equals_the_run_by_run_driver(monkeypatch):
     UniformInRunTwo.poison = float(B.vb_init(X.shape[0], X.shape[1], X, 3, hyper={"aw": 1.0, "ah": 1.0, "bw": 1.0, "bh": 1.0},
                                              initializer="random", rng=rng)["lw"][0, 0])
     results = []
-    for batched in (False, True):
+    for mode in ("run by run", "rank by rank", "across ranks", "across ranks, everything at once"):
         bundle = B.make_bundle(X, engine_factory=factory, **kw)
         bundle["device_loop"] = False
         bundle["concurrent"] = 1
         bundle["engines"] = {}
         B.plan_geometry(bundle, 1)
+        if mode.startswith("across"):
+            bundle["pad_rank"] = 4                                               # (what lets a batch span ranks; the numpy engine has no width)
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            vb = B.vb_iterate_batched(bundle, 2) if batched else [B.vb_iterate(irun, bundle) for irun in range(1, nrun + 1)]
+            vb = ([B.vb_iterate(irun, bundle) for irun in range(1, nrun + 1)] if mode == "run by run" else
+                  B.vb_iterate_batched(bundle, {"rank by rank": 2, "across ranks": 4}.get(mode, 64)))
         B._close_engines(bundle)
         results.append(vb)
-    for a, b in zip(*results):
-        assert a["rdat"] == b["rdat"] and a["nsteps"] == b["nsteps"] and a["hyperp"] == b["hyperp"]
-        for k in a["wdat"]:
-            assert np.array_equal(a["wdat"][k], b["wdat"][k]) and np.array_equal(a["hdat"][k], b["hdat"][k])
-    assert results[1][1]["rdat"][1] == -math.inf and results[1][1]["rdat"][2] == -math.inf      # run 2 stopped at rank 3 ...
-    assert results[1][0]["rdat"][2] > -math.inf and results[1][2]["rdat"][2] > -math.inf        # ... runs 1 and 3 went on
+    for other in results[1:]:
+        for a, b in zip(results[0], other):
+            assert a["rdat"] == b["rdat"] and a["nsteps"] == b["nsteps"] and a["hyperp"] == b["hyperp"]
+            for k in a["wdat"]:
+                assert np.array_equal(a["wdat"][k], b["wdat"][k]) and np.array_equal(a["hdat"][k], b["hdat"][k])
+        assert other[1]["rdat"][1] == -math.inf and other[1]["rdat"][2] == -math.inf        # run 2 stopped at rank 3 (its rank 4, run
+        assert other[0]["rdat"][2] > -math.inf and other[2]["rdat"][2] > -math.inf          # ahead across ranks, is dropped); 1 and 3 went on
     # what decides whether vb_factorize batches, and on which grids
     bundle = B.make_bundle(X, **dict(kw, nrun=5))
     bundle.update(device_loop=True, concurrent=1)
-    assert B.batch_eligible(bundle, None) == 5 and B.batch_eligible(bundle, 1) == 1 and B.batch_eligible(bundle, 3) == 3
-    assert B.batch_eligible(dict(bundle, nrun=40), None) == 16 and B.batch_eligible(dict(bundle, nrun=1), None) == 1
+    assert B.batch_eligible(bundle, None, False) == 5 and B.batch_eligible(bundle, 1) == 1 and B.batch_eligible(bundle, 3, False) == 3
+    assert B.batch_eligible(bundle, None) == 15 and B.batch_across_ranks(bundle, None) and not B.batch_across_ranks(dict(bundle, ranks=[3]), None)
+    assert B.batch_eligible(dict(bundle, nrun=40), None) == 16 and B.batch_eligible(dict(bundle, nrun=1), None) == 3      # (nrun = 1: the ranks)
+    assert B.batch_eligible(dict(bundle, nrun=1), None, False) == 1 and B.batch_eligible(dict(bundle, nrun=1, ranks=[3]), None) == 1
     assert E.auto_batch(3e5, 20) == 16 and E.auto_batch(2e6, 20) == 8 and E.auto_batch(1.5e7, 20) == 4 and E.auto_batch(5e7, 20) == 1 and E.auto_batch(3e5, 3) == 3
     assert B.batch_eligible(dict(bundle, ranks=[2, 17]), None) == 1 and B.batch_eligible(dict(bundle, concurrent=4), None) == 1
     with pytest.raises(ValueError):
-        B.batch_eligible(dict(bundle, nrun=1), 4)
+        B.batch_eligible(dict(bundle, nrun=1, ranks=[3]), 4)
     assert E.batch_grid(1) == (256, 256) and E.batch_grid(8) == (32, 32) and E.batch_grid(5) == (48, 48) and E.batch_grid(64) == (8, 8)

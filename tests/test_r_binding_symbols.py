@@ -66,7 +66,7 @@ def test_every_c_abi_call_of_the_r_sources_is_declared_with_the_same_arity():
     for must in ("vbnmf_update_dense", "vbnmf_last_error", "vbnmf_engine_create_geom", "vbnmf_engine_set_state", "vbnmf_engine_step",
                  "vbnmf_engine_run", "vbnmf_engine_get_state", "vbnmf_matrix_from_csc", "vbnmf_matrix_from_dense", "vbnmf_matrix_from_mtx",
                  "vbnmf_engine_ml_step", "vbnmf_comm_create", "vbnmf_engine_attach_comm", "vbnmf_engine_allreduce", "vbnmf_batch_run",
-                 "vbnmf_set_engine_grid", "vbnmf_batch_ml_run"):
+                 "vbnmf_set_engine_grid", "vbnmf_batch_ml_run", "vbnmf_set_engine_padding"):
         assert must in seen, must
 
 
