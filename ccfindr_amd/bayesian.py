@@ -423,8 +423,8 @@ def batch_across_ranks(bundle, across):
     """Whether a batch also takes several RANKS of the rank loop (reference R/bayesian.R:316): the engines of all ranks are then
     made one row width wide (the widest rank's), which costs the narrow ranks idle columns in the sweep -- nothing on a matrix
     whose step is latency bound anyway.  ``across`` as given, or -- ``None`` -- up to 2e6 stored entries."""
-    if len(bundle["ranks"]) < 2 or across is False:
-        return False
+    if len(bundle["ranks"]) < 2 or across is False or len(bundle.get("classes") or []) > 1:      # (several geometry classes: several
+        return False                                                                              # pairs of layouts, no common batch)
     return True if across else bundle["mat"].nnz <= 2_000_000
 
 
