@@ -558,6 +558,8 @@ bool build_update_table(const Layout &LA, const Layout &LB, int ub, int R, std::
     struct Item { int32_t cost; uint32_t code; int32_t cnt; };
     struct Plan { std::vector<std::vector<Item>> rows; int64_t ids = 0; int vmax = 0; };
     std::vector<Plan> plans(ub);
+    // (a thread per 16 K majors: on a small matrix starting threads costs more than the table -- 1 ms of a 1.7 ms engine creation)
+    const int table_threads = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), (nm[0] + nm[1]) >> 14));
     parallel_for(ub, [&](int64_t b0, int64_t b1, int) {
         std::vector<Item> items;
         for (int64_t b = b0; b < b1; b++) {
@@ -586,7 +588,7 @@ bool build_update_table(const Layout &LA, const Layout &LB, int ub, int R, std::
                 P.vmax = std::max(P.vmax, (int)P.rows[q].size());
             }
         }
-    });
+    }, table_threads);
     int64_t max_ids = 0;
     V = 1;
     for (const Plan &P : plans) { max_ids = std::max(max_ids, P.ids); V = std::max(V, (int32_t)P.vmax); }
@@ -623,7 +625,7 @@ bool build_update_table(const Layout &LA, const Layout &LB, int ub, int R, std::
                 for (; v < V; v++) { vis[3 * v] = 0xFFFFFFFFu; vis[3 * v + 1] = 0; vis[3 * v + 2] = 0; }
             }
         }
-    });
+    }, table_threads);
     return true;
 }
 
