@@ -40,7 +40,8 @@ that second call finds the sweep's layouts already cut); at N > 1
 also `cells_partitioned` = config C5 (one factorisation, cells partitioned N-way, the library's all-reduce inside the
 device-driven loop) with its per-GPU roofline and `allreduce_ms` (events around the collective); at N = 1 also
 `restarts_small_matrix` = the reference's own size class (1030 x 450): sixteen restarts of a rank one loop at a time against
-all sixteen stepped by one launch (vbnmf_batch_run), aggregate iterations per second.
+all sixteen stepped by one launch (vbnmf_batch_run), aggregate iterations per second; and `rank_sweep_nrun1` inside it: the
+reference's default call shape, `vb_factorize(ranks = 2..9, nrun = 1)`, one loop at a time against one batch over the ranks.
 
 N > 1 (one process per GPU under torch.distributed.run; a BARE `python bench.py --gpus N` starts those ranks itself as a
 child process -- before torch is imported or the GPU touched -- relays rank 0's line and exits with their status):
@@ -407,6 +408,16 @@ def small_matrix_restarts_sample():
             eng.close()
     out["speedup"] = out["batched"]["iterations_per_s"] / out["one_at_a_time"]["iterations_per_s"]
     out["lkh_rel_diff"] = abs(out["batched"]["lkh_first"] / out["one_at_a_time"]["lkh_first"] - 1)
+    # the reference's DEFAULT call has nrun = 1: then the units are the ranks of the sweep (engines made one row width wide share a batch)
+    kw = dict(ranks=range(2, 10), nrun=1, verbose=0, Tol=0.0, seed=5, Itmax=iters, unif_stop=False)
+    C.vb_factorize(M, **kw)                                       # (layouts of this geometry cut and cached)
+    sweep = {"workload": f"vb_factorize(ranks = 2..9, nrun = 1), {iters} iterations per rank, on the same matrix"}
+    for label, extra in (("one_at_a_time_s", dict(batch=1)), ("batched_s", {})):
+        t0 = time.perf_counter()
+        C.vb_factorize(M, **kw, **extra)
+        sweep[label] = time.perf_counter() - t0
+    sweep["speedup"] = sweep["one_at_a_time_s"] / sweep["batched_s"]
+    out["rank_sweep_nrun1"] = sweep
     M.close()
     return out
 
